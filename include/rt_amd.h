@@ -1,0 +1,176 @@
+/*
+ * rt_amd.h -- C ABI of the MI355X (gfx950) path tracer.
+ *
+ * The library is a drop-in for the render path of wak31415/raytracer:
+ * everything the reference does between Scene::render() and the returned
+ * image (reference src/scene.cu:209-222 -> src/raytrace.cu:509-644) sits
+ * behind these entry points.  All signatures are plain C: pointers, sizes
+ * and POD structs.  Every function returns 0 on success or a negative
+ * RT_ERR_* code; rt_last_error() gives the message of the calling thread's
+ * most recent failure.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)  /* bad argument / inconsistent description   */
+#define RT_ERR_DEVICE (-2)   /* a HIP call failed (message has the detail) */
+#define RT_ERR_IO (-3)       /* file missing or unreadable                 */
+#define RT_ERR_PARSE (-4)    /* malformed scene / mesh file                */
+#define RT_ERR_NOMEM (-5)
+
+/* material_type of the reference (include/scene_objects.cuh:4-8) */
+enum { RT_DIFFUSE = 0, RT_MIRROR = 1, RT_GLASS = 2 };
+
+/* Host-side scene description: the reference's raytrace_spheres() argument
+ * list (src/raytrace.cu:509-522) as flat arrays.  The Material copy the
+ * reference keeps in every Sphere and Triangle (include/scene_objects.cuh:
+ * 24-43) is an index into one material table here.  All pointers are host
+ * pointers owned by the caller; rt_scene_upload copies what it needs. */
+typedef struct rt_scene_desc {
+    uint32_t n_spheres;
+    const float* sphere_pos;        /* 3 * n_spheres */
+    const float* sphere_radius;     /* n_spheres */
+    const int32_t* sphere_material; /* n_spheres, index into materials */
+    uint32_t n_materials;
+    const int32_t* material_type;   /* RT_DIFFUSE / RT_MIRROR / RT_GLASS */
+    const float* material_color;    /* 3 * n_materials */
+    const float* material_ro;       /* refractive index outside */
+    const float* material_ri;       /* refractive index inside  */
+    uint32_t n_vertices;
+    const float* vertices;          /* 3 * n_vertices */
+    const float* normals;           /* 3 * n_vertices */
+    uint32_t n_triangles;
+    const int32_t* tri_v;           /* 3 * n_triangles, into vertices */
+    const int32_t* tri_n;           /* 3 * n_triangles, into normals  */
+    const int32_t* tri_material;    /* n_triangles */
+    uint32_t n_boxes;               /* the reference's obj_count */
+    const float* box_min;           /* 3 * n_boxes */
+    const float* box_max;           /* 3 * n_boxes */
+    uint32_t n_lights;
+    const float* light_pos;         /* 3 * n_lights */
+    const float* light_intensity;   /* n_lights */
+} rt_scene_desc;
+
+/* What the reference passes to its kernel from struct Camera
+ * (src/raytrace.cu:538-539,590-595): the rotation block and translation
+ * column of the extrinsic matrix E, the four intrinsics the kernel reads
+ * (K[0][0], K[1][1], K[0][2], K[1][2]; include/projection_helpers.cuh:69-75),
+ * the resolution and the samples per pixel. */
+typedef struct rt_camera {
+    float rot[9]; /* row-major */
+    float pos[3];
+    float fx, fy, cx, cy;
+    uint32_t width, height, num_rays;
+} rt_camera;
+
+/* The reference's compile-time switches INDIRECT_LIGHTING / ANTIALIASING /
+ * BOUNDING_BOX and MAX_RAY_DEPTH (src/raytrace.cu:12-16) as run-time
+ * options.  seed replaces time(0)+seed (src/raytrace.cu:574): the same seed
+ * always gives the same image. */
+typedef struct rt_options {
+    int32_t indirect;
+    int32_t antialiasing;
+    int32_t bounding_box;
+    int32_t max_depth; /* 5 in the reference */
+    uint32_t seed;
+    int32_t profile;   /* non-zero: time the triangle kernel with events */
+} rt_options;
+
+/* Work executed by the most recent render / accumulate call. */
+typedef struct rt_stats {
+    double gpu_ms;             /* first kernel start -> last kernel end        */
+    double mesh_kernel_ms;     /* summed over launches (profile != 0 only)     */
+    uint32_t mesh_kernel_launches;
+    uint32_t batches;
+    uint64_t paths;
+    uint64_t mesh_rays;        /* rays that walked the triangle list           */
+    uint64_t triangle_tests;   /* mesh_rays * n_triangles                      */
+    uint64_t sphere_casts;     /* casts tested against every sphere            */
+} rt_stats;
+
+typedef struct rt_scene rt_scene; /* device-resident scene */
+
+/* Selects the HIP device this thread renders on (hipSetDevice). */
+int rt_init(int32_t device);
+const char* rt_last_error(void);
+
+/* Replaces the per-call cudaMalloc + cudaMemcpy block of the reference
+ * (src/raytrace.cu:541-555): builds the structure-of-arrays device copy
+ * once, so several frames can be rendered from it. */
+int rt_scene_upload(const rt_scene_desc* desc, rt_scene** out_scene);
+int rt_scene_free(rt_scene* scene);
+
+/* Replaces raytrace_spheres() (src/raytrace.cu:509-644) for one device:
+ * renders cam->num_rays samples per pixel and writes the reference's output
+ * value per pixel, gamma((1/actual_rays) * colour) on the 0..255+ scale,
+ * unclamped, to out_rgb (host, 3 * width * height floats, row 0 on top). */
+int rt_render(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
+              float* out_rgb, rt_stats* stats);
+
+/* Multi-device building blocks (no counterpart in the single-GPU
+ * reference; they split its sample loop, src/raytrace.cu:478-500).
+ * rt_accumulate renders the GLOBAL sample indices [sample_begin, sample_end)
+ * of every pixel and ADDS the linear colour sums and the sample counts to
+ * d_sum (DEVICE memory, 4 * width * height floats: r, g, b, actual_rays),
+ * in sample order.  rt_resolve turns such a buffer -- after the per-device
+ * buffers were summed -- into the output image on the device.  `stream` is
+ * a hipStream_t (NULL = default stream); both calls only enqueue work. */
+int rt_accumulate(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
+                  uint32_t sample_begin, uint32_t sample_end, float* d_sum,
+                  void* stream, rt_stats* stats);
+int rt_resolve(const float* d_sum, uint32_t n_pixels, float* d_out_rgb, void* stream);
+
+/* Per-function entry points for known-answer tests.
+ * rt_cast = get_intersection (src/raytrace.cu:179-216) for n rays given as
+ * host arrays; out_t is +inf on a miss, ids are -1 when that kind is not
+ * the nearest hit, out_abg (3n) is written for triangle hits only.
+ * rt_visible = is_visible (src/raytrace.cu:218-244) for n segments. */
+int rt_cast(rt_scene* scene, const rt_options* opt, uint32_t n, const float* origins,
+            const float* dirs, float* out_t, int32_t* out_sphere, int32_t* out_triangle,
+            float* out_abg);
+int rt_visible(rt_scene* scene, const rt_options* opt, uint32_t n, const float* origins,
+               const float* targets, int32_t* out_visible);
+
+/* ---- host scene API: C view of class Scene ------------------------------
+ * Mirrors the reference's public Scene interface (include/scene.cuh:8-31);
+ * each function names the method it wraps. */
+typedef struct rt_host_scene rt_host_scene;
+
+int rt_host_scene_create(rt_host_scene** out);                       /* Scene::Scene      */
+int rt_host_scene_destroy(rt_host_scene* s);                          /* Scene::~Scene     */
+int rt_host_scene_load(rt_host_scene* s, const char* json_path);      /* load_scene        */
+int rt_host_scene_set_camera_intrinsics(rt_host_scene* s, float fov, size_t width, size_t height);
+int rt_host_scene_rotate_camera(rt_host_scene* s, float alpha, float beta, float gamma);
+int rt_host_scene_transform_camera(rt_host_scene* s, float x, float y, float z);
+int rt_host_scene_set_num_rays(rt_host_scene* s, uint32_t num_rays);
+int rt_host_scene_add_sphere(rt_host_scene* s, const float pos[3], float radius,
+                             const float color[3], int32_t material_type, float ro, float ri);
+int rt_host_scene_add_object(rt_host_scene* s, const char* obj_path, const float pos[3],
+                             const float scale[3], const float rotation[3],
+                             const float color[3], int32_t material_type, float ro, float ri);
+int rt_host_scene_add_light(rt_host_scene* s, const float pos[3], float intensity);
+int rt_host_scene_set_options(rt_host_scene* s, const rt_options* opt);
+/* Scene::render: renders on the current device, clamps to 8 bits like the
+ * reference (src/scene.cu:214-220) and writes an RGB PNG.  png_path may be
+ * NULL to skip the file. */
+int rt_host_scene_render(rt_host_scene* s, const char* png_path, size_t seed);
+/* Borrowed views, valid until the scene is modified or destroyed. */
+int rt_host_scene_describe(rt_host_scene* s, rt_scene_desc* out_desc, rt_camera* out_cam);
+const float* rt_host_scene_image(rt_host_scene* s, uint32_t* out_width, uint32_t* out_height);
+
+/* Encodes an 8-bit RGB image as PNG (the job stbi_write_png does in the
+ * reference, src/scene.cu:221). */
+int rt_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,1074 @@
+// pathtrace.hip -- gfx950 kernels and the device half of the C ABI.
+//
+// The reference runs one CUDA thread per pixel through the whole sample and
+// bounce loop (reference src/raytrace.cu:446-507).  Here a frame is a batch of
+// independent PATHS (one per pixel and sample) advanced one bounce at a time:
+//
+//   k_generate           camera sample, nearest sphere, box test
+//   for each bounce:
+//     k_mesh             every queued ray against every triangle
+//     k_shade            hit selection, material response, shadow rays,
+//                        next ray, nearest sphere, box test
+//   k_mesh               shadow rays of the last bounce
+//   k_accumulate         per pixel: sum the sample colours in sample order
+//
+// Only rays that pass the bounding-box test are queued for k_mesh; the queue
+// is dense, so all 64 lanes of a wavefront walk the triangle list with work
+// to do.  In k_mesh a lane owns a ray and the triangle index is wave-uniform,
+// so triangle data comes in through scalar loads and lives in SGPRs.
+//
+// Arithmetic follows the reference expression by expression and this file is
+// compiled with -ffp-contract=off, so sums and products round separately as
+// they do in the reference's float code.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "rt_math.h"
+
+// ------------------------------------------------------------ error store
+
+static thread_local char g_error[512] = "";
+
+void rt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* rt_last_error(void) { return g_error; }
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            rt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RT_ERR_DEVICE;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+// ---------------------------------------------------------- device layout
+
+namespace {
+
+constexpr uint32_t kBlock = 256;            // threads per workgroup (4 wavefronts)
+constexpr uint32_t kMeshChunk = 512;        // triangles per k_mesh job
+constexpr uint32_t kMeshGrid = 256 * 8;     // persistent k_mesh grid: 8 workgroups per CU
+constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none)
+constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
+constexpr uint32_t kMaxLights = 64;
+
+constexpr uint32_t F_ALIVE = 1u;   // the path still bounces
+constexpr uint32_t F_PENDING = 2u; // pend[] holds light contributions of the last hit
+constexpr uint32_t F_EARLY = 4u;   // the reference's terminate_early for this sample
+
+constexpr float PEND_NONE = -2.f;   // slot unused
+constexpr float PEND_ALWAYS = -1.f; // contribution known to be visible
+
+// Structure-of-arrays scene in HBM.  Every array is read with a wave-uniform
+// index except tri_shade / mat_* at shading time.
+struct DeviceScene {
+    const float4* sphere;     // centre.xyz, radius
+    const int32_t* sphere_mat;
+    const float4* mat_color;  // colour.xyz, type as int bits
+    const float2* mat_ior;    // ro, ri
+    const float4* tri_geom;   // 3 per triangle: A.xyz e1.x | e1.yz e2.xy | e2.z N.xyz
+    const float4* tri_shade;  // 3 per triangle: n0.xyz material | n1.xyz - | n2.xyz -
+    const float4* box_min;
+    const float4* box_max;
+    const float4* light;      // position.xyz, intensity
+    uint32_t n_spheres, n_triangles, n_boxes, n_lights;
+};
+
+// Per-batch path state and queues.
+struct Work {
+    float4* ray_o;   // origin.xyz, nearest-sphere distance
+    float4* ray_d;   // direction.xyz, nearest-sphere index as int bits
+    float4* thr;     // albedo.xyz, next random dimension as uint bits
+    float4* rad;     // colour L.xyz, F_* flags as uint bits
+    float4* pend;    // n_lights per path: contribution.xyz, light distance or PEND_*
+    unsigned long long* hit; // paths + paths*n_lights slots: (t bits << 32) | triangle
+    float4* q_o;     // queued ray origin.xyz, hit slot as uint bits
+    float4* q_d;     // queued ray direction.xyz
+    uint32_t* q_count; // one counter per k_mesh launch of a batch
+};
+
+struct V3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+// scalar of type double: product in double, one rounding to float
+// (reference include/vector.cuh:153-160 with S = double)
+__device__ __forceinline__ V3 scale_d(double s, V3 a) {
+    return mk((float)(s * (double)a.x), (float)(s * (double)a.y), (float)(s * (double)a.z));
+}
+// in-order dot product.  The reference starts the sum at 0.f
+// (include/vector.cuh:179-183); 0.f + p equals p except that it turns -0 into
+// +0, which no consumer of these dots can observe (they feed squares,
+// comparisons against 0 and quotients that are rejected when the divisor is
+// a zero of either sign).
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// the same with the explicit leading zero, for the few places that divide by
+// the result of a dot with an axis vector
+__device__ __forceinline__ float dot_z(V3 a, V3 b) { return ((0.f + a.x * b.x) + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float norm(V3 a) { return sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ __forceinline__ V3 normalize(V3 a) {
+    const float n = norm(a);
+    return mk(a.x / n, a.y / n, a.z / n);
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
+
+// ---------------------------------------------------------- intersection
+
+// Nearest sphere along a ray (reference get_distance, src/raytrace.cu:53-87).
+__device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, V3 ray, V3 start, int& id) {
+    float min_dist = INFINITY;
+    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+        const float4 s = sc.sphere[i];
+        const V3 oc = start - xyz(s);
+        const float b = dot(ray, oc);
+        const float ocn = norm(oc);
+        const float R = s.w;
+        const float delta = b * b - ocn * ocn + R * R;
+        if (delta >= 0) {
+            const float sq = sqrtf(delta);
+            const float t2 = -b + sq;
+            if (t2 >= 0) {
+                const float t1 = -b - sq;
+                const float t = t1 >= 0 ? t1 : t2;
+                if (id < 0 || t < min_dist) { min_dist = t; id = (int)i; }
+            }
+        }
+    }
+    return min_dist;
+}
+
+// Slab test against every box until one is hit (reference
+// src/raytrace.cu:103-145): per axis the entry/exit parameters stay 0 when
+// the ray is parallel to the slab, there is no t > 0 requirement, and the
+// verdict is min(exit) > max(entry).
+__device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, V3 ray, V3 start) {
+    const V3 axis[3] = {mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1)};
+    for (uint32_t o = 0; o < sc.n_boxes; o++) {
+        const V3 lo = xyz(sc.box_min[o]) - start;
+        const V3 hi = xyz(sc.box_max[o]) - start;
+        float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float rdn = dot_z(ray, axis[i]);
+            if (rdn != 0) {
+                const float a = dot_z(lo, axis[i]) / rdn;
+                const float b = dot_z(hi, axis[i]) / rdn;
+                if (a < b) { t0[i] = a; t1[i] = b; }
+                else       { t0[i] = b; t1[i] = a; }
+            }
+        }
+        // running min / max seeded with element 0 (reference include/vector.cuh:69-85)
+        float mn = t1[0];
+        if (t1[1] < mn) mn = t1[1];
+        if (t1[2] < mn) mn = t1[2];
+        float mx = t0[0];
+        if (t0[1] > mx) mx = t0[1];
+        if (t0[2] > mx) mx = t0[2];
+        if (mn > mx) return true;
+    }
+    return false;
+}
+
+// Appends the rays of the lanes with want == true to the k_mesh queue: one
+// atomic per wavefront, slots in lane order.
+__device__ __forceinline__ void enqueue(const Work& w, uint32_t counter, bool want, V3 start, V3 ray, uint32_t slot) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&w.q_count[counter], (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (want) {
+        const uint32_t at = base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
+        w.q_o[at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot));
+        w.q_d[at] = make_float4(ray.x, ray.y, ray.z, 0.f);
+    }
+}
+
+// True when the ray has to walk the triangle list (reference
+// src/raytrace.cu:103-146: with boxes enabled only after a box hit).
+__device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, int use_boxes, V3 ray, V3 start) {
+    if (sc.n_triangles == 0) return false;
+    if (!use_boxes) return true;
+    return any_box_hit(sc, ray, start);
+}
+
+// Barycentrics of a known hit, by the expressions of the reference's triangle
+// loop (src/raytrace.cu:155-164).
+__device__ __forceinline__ void barycentrics(const DeviceScene& sc, int tri, V3 ray, V3 start, float& alpha, float& beta, float& gamma) {
+    const float4 g0 = sc.tri_geom[3 * tri + 0], g1 = sc.tri_geom[3 * tri + 1], g2 = sc.tri_geom[3 * tri + 2];
+    const V3 A = mk(g0.x, g0.y, g0.z), e1 = mk(g0.w, g1.x, g1.y), e2 = mk(g1.z, g1.w, g2.x), N = mk(g2.y, g2.z, g2.w);
+    const V3 q = cross(A - start, ray);
+    const float d = dot(ray, N);
+    beta = dot(e2, q) / d;
+    gamma = -dot(e1, q) / d;
+    alpha = 1.f - beta - gamma;
+}
+
+// ------------------------------------------------------------- k_mesh
+
+// Every queued ray against every triangle (reference src/raytrace.cu:148-175).
+// A job is 256 rays x one chunk of triangles; the nearest hit per ray is
+// merged across chunks with a 64-bit atomic minimum on (t bits, triangle),
+// which orders by distance first and by triangle index second, i.e. the
+// reference's "first triangle wins ties" rule.
+//
+// Per triangle a lane first evaluates the reference's numerators and
+// denominator (bit-identical values) and a division-free test with an
+// approximate reciprocal; only lanes that may be inside the triangle take the
+// exact path with the reference's three IEEE divisions.  A reference-accepted
+// hit has alpha, beta, gamma in [0, 1], where the approximate values are off
+// by < 1e-6, so the 1e-5 margin never drops one; a NaN passes the test.
+__global__ __launch_bounds__(kBlock) void k_mesh(const float4* __restrict__ tri, uint32_t n_tri,
+                                                 const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                 const uint32_t* __restrict__ q_count,
+                                                 unsigned long long* __restrict__ hit) {
+    const uint32_t count = *q_count;
+    const uint32_t n_chunks = (n_tri + kMeshChunk - 1) / kMeshChunk;
+    const uint32_t n_jobs = ((count + kBlock - 1) / kBlock) * n_chunks;
+    for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+        const uint32_t ray_block = job / n_chunks;
+        const uint32_t chunk = job - ray_block * n_chunks;
+        const uint32_t r = ray_block * kBlock + threadIdx.x;
+        const bool active = r < count;
+        const uint32_t rr = active ? r : count - 1; // idle lanes shadow a real ray
+        const float4 o4 = q_o[rr];
+        const float4 d4 = q_d[rr];
+        const float ox = o4.x, oy = o4.y, oz = o4.z;
+        const float ux = d4.x, uy = d4.y, uz = d4.z;
+        float best = INFINITY;
+        int best_i = -1;
+        const uint32_t first = chunk * kMeshChunk;
+        const uint32_t last = min(first + kMeshChunk, n_tri);
+#pragma unroll 2
+        for (uint32_t i = first; i < last; i++) {
+            const float4 g0 = tri[3 * i + 0];
+            const float4 g1 = tri[3 * i + 1];
+            const float4 g2 = tri[3 * i + 2];
+            const float aox = g0.x - ox, aoy = g0.y - oy, aoz = g0.z - oz;
+            const float qx = aoy * uz - aoz * uy;
+            const float qy = aoz * ux - aox * uz;
+            const float qz = aox * uy - aoy * ux;
+            const float d = (ux * g2.y + uy * g2.z) + uz * g2.w;
+            const float nb = (g1.z * qx + g1.w * qy) + g2.x * qz; // e2 . q
+            const float ng = (g0.w * qx + g1.x * qy) + g1.y * qz; // e1 . q
+            const float rcp = __builtin_amdgcn_rcpf(d);
+            const float b_ = nb * rcp;
+            const float g_ = -ng * rcp;
+            const float a_ = (1.f - b_) - g_;
+            const float lo = fminf(fminf(a_, b_), g_);
+            if (!(lo < -1e-5f)) {
+                const float beta = nb / d;
+                const float gamma = -ng / d;
+                const float alpha = 1.f - beta - gamma;
+                if (alpha >= 0 && beta >= 0 && gamma >= 0) {
+                    const float t = ((aox * g2.y + aoy * g2.z) + aoz * g2.w) / d;
+                    if (t > 0 && (best_i < 0 || t < best)) { best = t; best_i = (int)i; }
+                }
+            }
+        }
+        if (active && best_i >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)best_i;
+            atomicMin(&hit[__float_as_uint(o4.w)], key);
+        }
+    }
+}
+
+// ------------------------------------------------------- path kernels
+
+struct Frame {
+    float rot[9];
+    float pos[3];
+    float fx, fy, cx, cy;
+    uint32_t width, n_pixels;
+    uint32_t n_paths;       // paths in this batch = n_pixels * samples in batch
+    uint32_t sample_begin;  // global index of the batch's first sample
+    uint32_t seed;
+    int32_t indirect, antialiasing, bounding_box, max_depth;
+};
+
+__device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return p % f.n_pixels; }
+__device__ __forceinline__ uint32_t path_sample(const Frame& f, uint32_t p) { return f.sample_begin + p / f.n_pixels; }
+
+// Nearest sphere + box test for a freshly generated ray, state write-back,
+// queueing for k_mesh.  All lanes of the wavefront must call it.
+__device__ __forceinline__ void launch_ray(const DeviceScene& sc, const Work& w, const Frame& f, uint32_t counter,
+                                           bool alive, uint32_t p, V3 start, V3 ray) {
+    int sid = -1;
+    float ts = INFINITY;
+    bool walk = false;
+    if (alive) {
+        ts = nearest_sphere(sc, ray, start, sid);
+        walk = needs_mesh(sc, f.bounding_box, ray, start);
+        w.ray_o[p] = make_float4(start.x, start.y, start.z, ts);
+        w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
+        w.hit[p] = kNoHit;
+    }
+    enqueue(w, counter, walk, start, ray, p);
+}
+
+// Camera sample of every path of the batch (reference src/raytrace.cu:479-494).
+__global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    const bool alive = p < f.n_paths;
+    V3 start = mk(f.pos[0], f.pos[1], f.pos[2]);
+    V3 ray = mk(0.f, 0.f, 1.f);
+    if (alive) {
+        const uint32_t pixel = path_pixel(f, p);
+        const uint32_t ux = pixel % f.width, uy = pixel / f.width;
+        const rt_rng_key key = rt_rng_make_key(f.seed, pixel, path_sample(f, p));
+        uint32_t dim = 0;
+        float dx = 0.f, dy = 0.f;
+        if (f.antialiasing) {
+            // Box-Muller pair, redrawn until both components are within half a
+            // pixel (reference src/raytrace.cu:33-42,483-486).  A draw with
+            // r1 < 0.77 has radius > 0.722 and max(|cos|,|sin|) >= 0.7071, so
+            // one component exceeds 0.5: it is rejected without evaluating the
+            // logarithm and the trigonometric pair.
+            dx = 1.f;
+            dy = 1.f;
+            while (fabsf(dx) > 0.5f || fabsf(dy) > 0.5f) {
+                const float r1 = rt_rng_uniform(key, dim);
+                const float r2 = rt_rng_uniform(key, dim + 1);
+                dim += 2;
+                if (r1 < 0.77f) continue;
+                const float radius = sqrtf(-2 * rt_logf(r1));
+                const float angle = (float)(2 * M_PI * (double)r2);
+                float sn, cs;
+                rt_sincosf(angle, &sn, &cs);
+                dx = radius * cs * 1.f;
+                dy = radius * sn * 1.f;
+            }
+        }
+        const float px = (float)ux + 0.5f + dx;
+        const float py = (float)uy + 0.5f + dy;
+        const V3 dir = normalize(mk((px - f.cx) / f.fx, (py - f.cy) / f.fy, 1.f));
+        ray = mk(dot(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
+                 dot(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
+                 dot(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
+        w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
+        w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
+    }
+    launch_ray(sc, w, f, 0, alive, p, start, ray);
+}
+
+// Adds the light contributions a path left pending at its previous hit, in
+// light order, now that k_mesh has answered its shadow rays.
+__device__ __forceinline__ V3 settle_pending(const DeviceScene& sc, const Work& w, uint32_t n_paths, uint32_t p, V3 L) {
+    for (uint32_t l = 0; l < sc.n_lights; l++) {
+        const float4 pe = w.pend[(size_t)p * sc.n_lights + l];
+        if (pe.w == PEND_NONE) continue;
+        bool visible = true;
+        if (pe.w != PEND_ALWAYS) {
+            const unsigned long long key = w.hit[(size_t)n_paths + (size_t)p * sc.n_lights + l];
+            visible = !(__uint_as_float((uint32_t)(key >> 32)) < pe.w);
+        }
+        if (visible) L = L + mk(pe.x, pe.y, pe.z);
+    }
+    return L;
+}
+
+// cosine-weighted direction about N (reference random_cos,
+// src/raytrace.cu:253-296, with argmin_abs of include/vector.cuh:87-98: the
+// running minimum starts at the signed first component)
+__device__ __forceinline__ V3 random_cos(float r1, float r2, V3 N) {
+    const float tmp1 = sqrtf(1 - r2);
+    const float tmp2 = (float)(2 * M_PI * (double)r1);
+    float sn, cs;
+    rt_sincosf(tmp2, &sn, &cs);
+    const float x = tmp1 * cs;
+    const float y = tmp1 * sn;
+    const float z = sqrtf(r2);
+    const float n[3] = {N.x, N.y, N.z};
+    float m = n[0];
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        if (fabsf(n[i]) < m) { m = fabsf(n[i]); k = i; }
+    V3 T1;
+    if (k == 0) T1 = mk(0.f, N.z, -N.y);       // (i, j) = (1, 2)
+    else if (k == 1) T1 = mk(-N.z, 0.f, N.x);  // (i, j) = (2, 0)
+    else T1 = mk(N.y, -N.x, 0.f);              // (i, j) = (0, 1)
+    T1 = normalize(T1);
+    const V3 T2 = normalize(cross(N, T1));
+    return (x * T1 + y * T2) + z * N;
+}
+
+__device__ __forceinline__ V3 reflect(V3 ray, V3 N) { return ray - (2 * dot(ray, N)) * N; }
+
+// One bounce of every live path (reference get_color loop body,
+// src/raytrace.cu:317-442).  `depth` is the bounce index; counter depth+1
+// receives the rays this bounce queues for k_mesh.
+__global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t counter = (uint32_t)depth + 1u;
+    bool alive = false;
+    V3 start = mk(0, 0, 0), ray = mk(0, 0, 1);
+    if (p < f.n_paths) {
+        float4 rad = w.rad[p];
+        uint32_t flags = __float_as_uint(rad.w);
+        if (flags & F_ALIVE) {
+            V3 L = mk(rad.x, rad.y, rad.z);
+            if (flags & F_PENDING) {
+                L = settle_pending(sc, w, f.n_paths, p, L);
+                flags &= ~F_PENDING;
+            }
+            const float4 ro4 = w.ray_o[p], rd4 = w.ray_d[p];
+            start = xyz(ro4);
+            ray = xyz(rd4);
+            const float ts = ro4.w;
+            int sid = __float_as_int(rd4.w);
+            const unsigned long long key = w.hit[p];
+            const float tt = __uint_as_float((uint32_t)(key >> 32));
+            int tid = (int)(uint32_t)key; // 0xffffffff -> -1
+
+            // nearer of the two, spheres win ties (reference get_intersection,
+            // src/raytrace.cu:194-215; `tmp` starts as the triangle id)
+            float min_dist = INFINITY;
+            int tmp = tid;
+            if (ts < min_dist) { min_dist = ts; tmp = tid; tid = -1; }
+            if (tt < min_dist) { min_dist = tt; sid = -1; tid = tmp; }
+
+            if (sid >= 0 || tid >= 0) {
+                const V3 P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : start + min_dist * ray;
+                V3 N;
+                int m;
+                if (sid >= 0) {
+                    m = sc.sphere_mat[sid];
+                    N = normalize(P - xyz(sc.sphere[sid]));
+                } else {
+                    float alpha, beta, gamma;
+                    barycentrics(sc, tid, ray, start, alpha, beta, gamma);
+                    const float4 s0 = sc.tri_shade[3 * tid + 0], s1 = sc.tri_shade[3 * tid + 1], s2 = sc.tri_shade[3 * tid + 2];
+                    m = __float_as_int(s0.w);
+                    N = normalize((alpha * xyz(s0) + beta * xyz(s1)) + gamma * xyz(s2));
+                }
+                const float4 mc = sc.mat_color[m];
+                const int type = __float_as_int(mc.w);
+                const V3 colour = xyz(mc);
+                float4 th = w.thr[p];
+                V3 albedo = xyz(th);
+                uint32_t dim = __float_as_uint(th.w);
+                const rt_rng_key rng = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
+                alive = true;
+
+                if (type == RT_DIFFUSE) {
+                    if (!f.indirect && depth == 0) flags |= F_EARLY;
+                    if (f.antialiasing) flags &= ~F_EARLY;
+                    const V3 lifted = P + scale_d(0.01, N);
+                    bool deferred = false;
+                    for (uint32_t l = 0; l < sc.n_lights; l++) {
+                        const float4 li = sc.light[l];
+                        const V3 lp = xyz(li);
+                        const V3 sp = lp - P;
+                        const float d = norm(sp);
+                        const V3 wi = (1.f / d) * sp;
+                        const float nwi = fmaxf(dot(N, wi), 0.f);
+                        // shadow ray (reference is_visible, src/raytrace.cu:218-244)
+                        const V3 sray = normalize(lp - lifted);
+                        int shadow_sid = -1;
+                        const float ds = nearest_sphere(sc, sray, lifted, shadow_sid);
+                        const float dist = norm(lp - lifted);
+                        const bool blocked = ds < dist;
+                        const bool walk = !blocked && needs_mesh(sc, f.bounding_box, sray, lifted);
+                        // ((I / (4 pi^2 d^2) * colour) * visible) * N.wi, the
+                        // first factor in double (reference src/raytrace.cu:360)
+                        const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
+                        const V3 direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
+                        const V3 c = albedo * direct;
+                        const size_t slot = (size_t)p * sc.n_lights + l;
+                        if (walk) {
+                            if (!deferred) // first pending light: clear the earlier slots
+                                for (uint32_t e = 0; e < l; e++) w.pend[(size_t)p * sc.n_lights + e].w = PEND_NONE;
+                            deferred = true;
+                            w.pend[slot] = make_float4(c.x, c.y, c.z, dist);
+                            w.hit[(size_t)f.n_paths + slot] = kNoHit;
+                        } else if (deferred) {
+                            w.pend[slot] = make_float4(c.x, c.y, c.z, PEND_ALWAYS);
+                        } else {
+                            L = L + c;
+                        }
+                        enqueue(w, counter, walk, lifted, sray, (uint32_t)(f.n_paths + slot));
+                    }
+                    if (deferred) flags |= F_PENDING;
+                    if (!f.indirect) {
+                        alive = false;
+                    } else {
+                        albedo = albedo * colour;
+                        start = lifted;
+                        const float r1 = rt_rng_uniform(rng, dim);
+                        const float r2 = rt_rng_uniform(rng, dim + 1);
+                        dim += 2;
+                        ray = random_cos(r1, r2, N);
+                    }
+                } else if (type == RT_MIRROR) {
+                    const V3 rr = reflect(ray, N);
+                    start = P + scale_d(0.01, N);
+                    ray = rr;
+                } else { // RT_GLASS
+                    const float2 ior = sc.mat_ior[m];
+                    float ro = ior.x, ri = ior.y;
+                    float wn = dot(ray, N);
+                    // Schlick reflectance (reference src/raytrace.cu:388-394)
+                    const float k0 = (ro - ri) * (ro - ri) / ((ro + ri) * (ro + ri));
+                    const float om = 1.f - fabsf(wn);
+                    const float om2 = om * om;
+                    const float R = k0 + (1.f - k0) * om2 * om2 * om;
+                    const float r = rt_rng_uniform(rng, dim);
+                    dim += 1;
+                    if (r < R) {
+                        const V3 rr = reflect(ray, N);
+                        start = P + scale_d(0.01, N);
+                        ray = rr;
+                    } else {
+                        if (wn > 0) { // leaving the medium: swap indices, flip the normal
+                            const float sw = ro; ro = ri; ri = sw;
+                            N = -1.f * N;
+                            wn = dot(ray, N);
+                        }
+                        const float eta = ro / ri;
+                        const float k = 1.f - eta * eta * (1.f - wn * wn);
+                        if (k < 0) { // total internal reflection
+                            const V3 rr = reflect(ray, N);
+                            start = P + scale_d(0.01, N);
+                            ray = rr;
+                        } else {
+                            const V3 wt_t = eta * (ray - wn * N);
+                            const V3 wt_n = (-sqrtf(k)) * N;
+                            start = P - scale_d(0.01, N);
+                            ray = wt_t + wt_n;
+                        }
+                    }
+                }
+                if (depth + 1 >= f.max_depth) alive = false;
+                w.thr[p] = make_float4(albedo.x, albedo.y, albedo.z, __uint_as_float(dim));
+            }
+            if (!alive) flags &= ~F_ALIVE;
+            w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
+        }
+    }
+    // NOTE: the per-light enqueue above runs inside divergent control flow;
+    // enqueue() is safe there because __ballot only counts active lanes.
+    launch_ray(sc, w, f, counter, alive, p, start, ray);
+}
+
+// Per pixel: add the batch's sample colours to the running sum in sample
+// order, as the reference's sample loop does (src/raytrace.cu:478-499).
+// sum[pixel] = (r, g, b, actual_rays).
+__global__ __launch_bounds__(kBlock) void k_accumulate(DeviceScene sc, Work w, Frame f, float4* __restrict__ sum) {
+    const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
+    if (pixel >= f.n_pixels) return;
+    float4 acc = sum[pixel];
+    const uint32_t n_samples = f.n_paths / f.n_pixels;
+    for (uint32_t s = 0; s < n_samples; s++) {
+        const uint32_t p = s * f.n_pixels + pixel;
+        const float4 rad = w.rad[p];
+        const uint32_t flags = __float_as_uint(rad.w);
+        V3 L = mk(rad.x, rad.y, rad.z);
+        if (flags & F_PENDING) L = settle_pending(sc, w, f.n_paths, p, L);
+        acc.x += L.x;
+        acc.y += L.y;
+        acc.z += L.z;
+        acc.w += 1.f;
+        if (!f.indirect && (flags & F_EARLY)) break;
+    }
+    sum[pixel] = acc;
+}
+
+// gamma((1/actual_rays) * colour) (reference src/raytrace.cu:44-51,500)
+__global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ sum, uint32_t n_pixels, float* __restrict__ out) {
+    const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
+    if (pixel >= n_pixels) return;
+    const float4 s = sum[pixel];
+    const float inv = 1.f / s.w;
+    out[3 * pixel + 0] = rt_gamma_encode(inv * s.x);
+    out[3 * pixel + 1] = rt_gamma_encode(inv * s.y);
+    out[3 * pixel + 2] = rt_gamma_encode(inv * s.z);
+}
+
+// ------------------------------------------- known-answer test kernels
+
+// rays -> state + queue, through the same launch_ray the renderer uses
+__global__ __launch_bounds__(kBlock) void k_probe_rays(DeviceScene sc, Work w, Frame f, const float* __restrict__ origins,
+                                                       const float* __restrict__ dirs, int as_segments) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    const bool alive = p < f.n_paths;
+    V3 start = mk(0, 0, 0), ray = mk(0, 0, 1);
+    if (alive) {
+        start = mk(origins[3 * p], origins[3 * p + 1], origins[3 * p + 2]);
+        ray = mk(dirs[3 * p], dirs[3 * p + 1], dirs[3 * p + 2]);
+        if (as_segments) { // `dirs` holds targets (reference is_visible)
+            const V3 target = ray;
+            ray = normalize(target - start);
+            w.thr[p] = make_float4(norm(target - start), 0.f, 0.f, 0.f);
+        }
+    }
+    launch_ray(sc, w, f, 0, alive, p, start, ray);
+}
+
+__global__ __launch_bounds__(kBlock) void k_probe_results(DeviceScene sc, Work w, Frame f, int as_segments, float* __restrict__ out_t,
+                                                          int32_t* __restrict__ out_sphere, int32_t* __restrict__ out_triangle,
+                                                          float* __restrict__ out_abg, int32_t* __restrict__ out_visible) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= f.n_paths) return;
+    const float4 ro4 = w.ray_o[p], rd4 = w.ray_d[p];
+    const float ts = ro4.w;
+    int sid = __float_as_int(rd4.w);
+    const unsigned long long key = w.hit[p];
+    const float tt = __uint_as_float((uint32_t)(key >> 32));
+    int tid = (int)(uint32_t)key;
+    if (as_segments) {
+        const float dist = w.thr[p].x;
+        out_visible[p] = (ts < dist || tt < dist) ? 0 : 1;
+        return;
+    }
+    float min_dist = INFINITY;
+    int tmp = tid;
+    if (ts < min_dist) { min_dist = ts; tmp = tid; tid = -1; }
+    if (tt < min_dist) { min_dist = tt; sid = -1; tid = tmp; }
+    out_t[p] = min_dist;
+    out_sphere[p] = sid;
+    out_triangle[p] = tid;
+    if (tid >= 0) {
+        float a, b, g;
+        barycentrics(sc, tid, xyz(rd4), xyz(ro4), a, b, g);
+        out_abg[3 * p] = a; out_abg[3 * p + 1] = b; out_abg[3 * p + 2] = g;
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------- host side
+
+struct rt_scene {
+    DeviceScene d{};
+    std::vector<void*> allocations;
+    // batch work buffers, grown on demand
+    Work w{};
+    std::vector<void*> work_allocations;
+    uint32_t work_paths = 0;
+    uint32_t n_counters = 0;
+    // profiling events
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+template <typename T>
+int upload(rt_scene* s, const std::vector<T>& host, const T** out) {
+    void* dev = nullptr;
+    const size_t bytes = (host.empty() ? 1 : host.size()) * sizeof(T);
+    HIP_TRY(hipMalloc(&dev, bytes));
+    s->allocations.push_back(dev);
+    if (!host.empty()) HIP_TRY(hipMemcpy(dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(dev);
+    return RT_OK;
+}
+
+int validate(const rt_scene_desc* d) {
+    if (!d) { rt_set_error("scene description is null"); return RT_ERR_INVALID; }
+    if ((d->n_spheres && !(d->sphere_pos && d->sphere_radius && d->sphere_material)) ||
+        (d->n_materials && !(d->material_type && d->material_color && d->material_ro && d->material_ri)) ||
+        (d->n_vertices && !(d->vertices && d->normals)) ||
+        (d->n_triangles && !(d->tri_v && d->tri_n && d->tri_material)) ||
+        (d->n_boxes && !(d->box_min && d->box_max)) || (d->n_lights && !(d->light_pos && d->light_intensity))) {
+        rt_set_error("scene description has a non-zero count with a null array");
+        return RT_ERR_INVALID;
+    }
+    if (d->n_lights > kMaxLights) { rt_set_error("at most %u lights are supported", kMaxLights); return RT_ERR_INVALID; }
+    if (d->n_triangles > 0x7fffffffu / 3 || d->n_spheres > 0x7fffffffu) { rt_set_error("scene too large"); return RT_ERR_INVALID; }
+    for (uint32_t i = 0; i < d->n_materials; i++)
+        if (d->material_type[i] < RT_DIFFUSE || d->material_type[i] > RT_GLASS) {
+            rt_set_error("material %u has unknown type %d", i, d->material_type[i]);
+            return RT_ERR_INVALID;
+        }
+    for (uint32_t i = 0; i < d->n_spheres; i++)
+        if (d->sphere_material[i] < 0 || (uint32_t)d->sphere_material[i] >= d->n_materials) {
+            rt_set_error("sphere %u refers to material %d of %u", i, d->sphere_material[i], d->n_materials);
+            return RT_ERR_INVALID;
+        }
+    for (uint32_t i = 0; i < d->n_triangles; i++) {
+        if (d->tri_material[i] < 0 || (uint32_t)d->tri_material[i] >= d->n_materials) {
+            rt_set_error("triangle %u refers to material %d of %u", i, d->tri_material[i], d->n_materials);
+            return RT_ERR_INVALID;
+        }
+        for (int k = 0; k < 3; k++)
+            if (d->tri_v[3 * i + k] < 0 || (uint32_t)d->tri_v[3 * i + k] >= d->n_vertices || d->tri_n[3 * i + k] < 0 ||
+                (uint32_t)d->tri_n[3 * i + k] >= d->n_vertices) {
+                rt_set_error("triangle %u refers to a vertex or normal outside [0, %u)", i, d->n_vertices);
+                return RT_ERR_INVALID;
+            }
+    }
+    return RT_OK;
+}
+
+int check_frame(const rt_scene* scene, const rt_camera* cam, const rt_options* opt) {
+    if (!scene || !cam || !opt) { rt_set_error("null scene, camera or options"); return RT_ERR_INVALID; }
+    if (cam->width == 0 || cam->height == 0 || (uint64_t)cam->width * cam->height > (1ull << 28)) {
+        rt_set_error("unsupported resolution %ux%u", cam->width, cam->height);
+        return RT_ERR_INVALID;
+    }
+    if (opt->max_depth < 0 || opt->max_depth > 64) { rt_set_error("max_depth %d outside [0, 64]", opt->max_depth); return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
+void free_work(rt_scene* s) {
+    for (void* p : s->work_allocations) (void)hipFree(p);
+    s->work_allocations.clear();
+    s->work_paths = 0;
+    s->n_counters = 0;
+    std::memset(&s->w, 0, sizeof s->w);
+}
+
+template <typename T>
+int work_alloc(rt_scene* s, T** out, size_t count) {
+    void* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, (count ? count : 1) * sizeof(T)));
+    s->work_allocations.push_back(dev);
+    *out = static_cast<T*>(dev);
+    return RT_OK;
+}
+
+// Work buffers for batches of up to n_paths paths and max_depth bounces.
+int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
+    if (s->work_paths >= n_paths && s->n_counters >= n_counters) return RT_OK;
+    free_work(s);
+    const size_t nl = s->d.n_lights ? s->d.n_lights : 1;
+    const size_t slots = (size_t)n_paths * (1 + nl);
+    int rc;
+    if ((rc = work_alloc(s, &s->w.ray_o, n_paths)) || (rc = work_alloc(s, &s->w.ray_d, n_paths)) ||
+        (rc = work_alloc(s, &s->w.thr, n_paths)) || (rc = work_alloc(s, &s->w.rad, n_paths)) ||
+        (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
+        (rc = work_alloc(s, &s->w.q_o, slots)) || (rc = work_alloc(s, &s->w.q_d, slots)) ||
+        (rc = work_alloc(s, &s->w.q_count, n_counters))) {
+        free_work(s);
+        return rc;
+    }
+    s->work_paths = n_paths;
+    s->n_counters = n_counters;
+    return RT_OK;
+}
+
+Frame make_frame(const rt_camera* cam, const rt_options* opt) {
+    Frame f;
+    std::memcpy(f.rot, cam->rot, sizeof f.rot);
+    std::memcpy(f.pos, cam->pos, sizeof f.pos);
+    f.fx = cam->fx; f.fy = cam->fy; f.cx = cam->cx; f.cy = cam->cy;
+    f.width = cam->width;
+    f.n_pixels = cam->width * cam->height;
+    f.n_paths = 0;
+    f.sample_begin = 0;
+    f.seed = opt->seed;
+    f.indirect = opt->indirect != 0;
+    f.antialiasing = opt->antialiasing != 0;
+    f.bounding_box = opt->bounding_box != 0;
+    f.max_depth = opt->max_depth;
+    return f;
+}
+
+int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile) {
+    if (s->d.n_triangles == 0) return RT_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        s->events.push_back(e0);
+        s->events.push_back(e1);
+        HIP_TRY(hipEventRecord(e0, stream));
+    }
+    hipLaunchKernelGGL(k_mesh, dim3(kMeshGrid), dim3(kBlock), 0, stream, s->d.tri_geom, s->d.n_triangles,
+                       (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)(s->w.q_count + counter), s->w.hit);
+    HIP_TRY(hipGetLastError());
+    if (profile) HIP_TRY(hipEventRecord(e1, stream));
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" int rt_init(int32_t device) {
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) { rt_set_error("rt_init: device %d of %d", device, count); return RT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    return RT_OK;
+}
+
+extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
+    if (!out) { rt_set_error("rt_scene_upload: null output"); return RT_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(d);
+    if (rc != RT_OK) return rc;
+
+    std::vector<float4> sphere(d->n_spheres);
+    std::vector<int32_t> sphere_mat(d->sphere_material, d->sphere_material + d->n_spheres);
+    for (uint32_t i = 0; i < d->n_spheres; i++)
+        sphere[i] = make_float4(d->sphere_pos[3 * i], d->sphere_pos[3 * i + 1], d->sphere_pos[3 * i + 2], d->sphere_radius[i]);
+    std::vector<float4> mat_color(d->n_materials);
+    std::vector<float2> mat_ior(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        float type_bits;
+        std::memcpy(&type_bits, &d->material_type[i], sizeof type_bits);
+        mat_color[i] = make_float4(d->material_color[3 * i], d->material_color[3 * i + 1], d->material_color[3 * i + 2], type_bits);
+        mat_ior[i] = make_float2(d->material_ro[i], d->material_ri[i]);
+    }
+    // Ray-independent part of the reference's per-test work, done once:
+    // e1 = B - A, e2 = C - A, N = e1 x e2 (reference src/raytrace.cu:155-158);
+    // plain float subtractions and products, so the stored values are the
+    // ones the reference recomputes for every ray.
+    std::vector<float4> geom(3 * (size_t)d->n_triangles), shade(3 * (size_t)d->n_triangles);
+    for (uint32_t i = 0; i < d->n_triangles; i++) {
+        const float* A = d->vertices + 3 * d->tri_v[3 * i + 0];
+        const float* B = d->vertices + 3 * d->tri_v[3 * i + 1];
+        const float* C = d->vertices + 3 * d->tri_v[3 * i + 2];
+        const float e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+        const float e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+        const float N[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        geom[3 * i + 0] = make_float4(A[0], A[1], A[2], e1[0]);
+        geom[3 * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
+        geom[3 * i + 2] = make_float4(e2[2], N[0], N[1], N[2]);
+        float mat_bits;
+        std::memcpy(&mat_bits, &d->tri_material[i], sizeof mat_bits);
+        for (int k = 0; k < 3; k++) {
+            const float* n = d->normals + 3 * d->tri_n[3 * i + k];
+            shade[3 * i + k] = make_float4(n[0], n[1], n[2], k == 0 ? mat_bits : 0.f);
+        }
+    }
+    std::vector<float4> box_min(d->n_boxes), box_max(d->n_boxes), light(d->n_lights);
+    for (uint32_t i = 0; i < d->n_boxes; i++) {
+        box_min[i] = make_float4(d->box_min[3 * i], d->box_min[3 * i + 1], d->box_min[3 * i + 2], 0.f);
+        box_max[i] = make_float4(d->box_max[3 * i], d->box_max[3 * i + 1], d->box_max[3 * i + 2], 0.f);
+    }
+    for (uint32_t i = 0; i < d->n_lights; i++)
+        light[i] = make_float4(d->light_pos[3 * i], d->light_pos[3 * i + 1], d->light_pos[3 * i + 2], d->light_intensity[i]);
+
+    rt_scene* s = new rt_scene();
+    s->d.n_spheres = d->n_spheres;
+    s->d.n_triangles = d->n_triangles;
+    s->d.n_boxes = d->n_boxes;
+    s->d.n_lights = d->n_lights;
+    if ((rc = upload(s, sphere, &s->d.sphere)) || (rc = upload(s, sphere_mat, &s->d.sphere_mat)) ||
+        (rc = upload(s, mat_color, &s->d.mat_color)) || (rc = upload(s, mat_ior, &s->d.mat_ior)) ||
+        (rc = upload(s, geom, &s->d.tri_geom)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
+        (rc = upload(s, box_min, &s->d.box_min)) || (rc = upload(s, box_max, &s->d.box_max)) ||
+        (rc = upload(s, light, &s->d.light))) {
+        rt_scene_free(s);
+        return rc;
+    }
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_free(rt_scene* s) {
+    if (!s) return RT_OK;
+    free_work(s);
+    for (void* p : s->allocations) (void)hipFree(p);
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    delete s;
+    return RT_OK;
+}
+
+extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin,
+                             uint32_t sample_end, float* d_sum, void* stream_, rt_stats* stats) {
+    int rc = check_frame(s, cam, opt);
+    if (rc != RT_OK) return rc;
+    if (!d_sum || sample_end < sample_begin) { rt_set_error("rt_accumulate: bad sample range or null buffer"); return RT_ERR_INVALID; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Frame f = make_frame(cam, opt);
+    const uint32_t n_pixels = f.n_pixels;
+    const uint32_t n_samples = sample_end - sample_begin;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n_samples == 0) return RT_OK;
+
+    uint32_t per_batch = kMaxPathsPerBatch / n_pixels;
+    if (per_batch == 0) per_batch = 1;
+    if (per_batch > n_samples) per_batch = n_samples;
+    const uint32_t n_counters = (uint32_t)opt->max_depth + 1u;
+    if ((rc = ensure_work(s, per_batch * n_pixels, n_counters)) != RT_OK) return rc;
+
+    const bool profile = stats && opt->profile;
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    s->events.clear();
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (stats) {
+        HIP_TRY(hipEventCreate(&t0));
+        HIP_TRY(hipEventCreate(&t1));
+        HIP_TRY(hipEventRecord(t0, stream));
+    }
+    std::vector<uint32_t> counts(n_counters);
+    uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
+    uint32_t batches = 0;
+
+    for (uint32_t first = 0; first < n_samples; first += per_batch) {
+        const uint32_t in_batch = (n_samples - first < per_batch) ? n_samples - first : per_batch;
+        f.n_paths = in_batch * n_pixels;
+        f.sample_begin = sample_begin + first;
+        const dim3 grid((f.n_paths + kBlock - 1) / kBlock), block(kBlock);
+        HIP_TRY(hipMemsetAsync(s->w.q_count, 0, n_counters * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_generate, grid, block, 0, stream, s->d, s->w, f);
+        HIP_TRY(hipGetLastError());
+        for (int depth = 0; depth < opt->max_depth; depth++) {
+            if ((rc = launch_mesh(s, (uint32_t)depth, stream, profile)) != RT_OK) return rc;
+            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, s->d, s->w, f, depth);
+            HIP_TRY(hipGetLastError());
+        }
+        if ((rc = launch_mesh(s, (uint32_t)opt->max_depth, stream, profile)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_accumulate, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, s->d, s->w, f,
+                           reinterpret_cast<float4*>(d_sum));
+        HIP_TRY(hipGetLastError());
+        batches++;
+        paths += f.n_paths;
+        if (stats) { // the counters are reused by the next batch: read them now
+            HIP_TRY(hipMemcpyAsync(counts.data(), s->w.q_count, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (uint32_t c = 0; c < n_counters; c++) mesh_rays += counts[c];
+        }
+    }
+    if (stats) {
+        HIP_TRY(hipEventRecord(t1, stream));
+        HIP_TRY(hipEventSynchronize(t1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+        stats->gpu_ms = ms;
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+        for (size_t i = 0; i + 1 < s->events.size(); i += 2) {
+            float k = 0.f;
+            HIP_TRY(hipEventElapsedTime(&k, s->events[i], s->events[i + 1]));
+            stats->mesh_kernel_ms += k;
+            stats->mesh_kernel_launches++;
+        }
+        stats->batches = batches;
+        stats->paths = paths;
+        stats->mesh_rays = mesh_rays;
+        stats->triangle_tests = mesh_rays * s->d.n_triangles;
+        stats->sphere_casts = sphere_casts;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_resolve(const float* d_sum, uint32_t n_pixels, float* d_out_rgb, void* stream_) {
+    if (!d_sum || !d_out_rgb || n_pixels == 0) { rt_set_error("rt_resolve: bad argument"); return RT_ERR_INVALID; }
+    hipLaunchKernelGGL(k_resolve, dim3((n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, static_cast<hipStream_t>(stream_),
+                       reinterpret_cast<const float4*>(d_sum), n_pixels, d_out_rgb);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* opt, float* out_rgb, rt_stats* stats) {
+    int rc = check_frame(s, cam, opt);
+    if (rc != RT_OK) return rc;
+    if (!out_rgb) { rt_set_error("rt_render: null output"); return RT_ERR_INVALID; }
+    const uint32_t n_pixels = cam->width * cam->height;
+    float* d_sum = nullptr;
+    float* d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_sum), (size_t)n_pixels * 4 * sizeof(float)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n_pixels * 3 * sizeof(float)) != hipSuccess) {
+        (void)hipFree(d_sum);
+        rt_set_error("rt_render: out of device memory");
+        return RT_ERR_NOMEM;
+    }
+    rt_stats local;
+    rc = (hipMemsetAsync(d_sum, 0, (size_t)n_pixels * 4 * sizeof(float), nullptr) == hipSuccess) ? RT_OK : RT_ERR_DEVICE;
+    if (rc == RT_OK) rc = rt_accumulate(s, cam, opt, 0, cam->num_rays, d_sum, nullptr, stats ? stats : &local);
+    if (rc == RT_OK) rc = rt_resolve(d_sum, n_pixels, d_out, nullptr);
+    if (rc == RT_OK && hipMemcpy(out_rgb, d_out, (size_t)n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        rt_set_error("rt_render: device to host copy failed");
+        rc = RT_ERR_DEVICE;
+    }
+    (void)hipFree(d_sum);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+namespace {
+
+int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const float* b, int as_segments, float* out_t,
+          int32_t* out_sphere, int32_t* out_triangle, float* out_abg, int32_t* out_visible) {
+    if (!s || !opt || !a || !b) { rt_set_error("probe: null argument"); return RT_ERR_INVALID; }
+    if (n == 0) return RT_OK;
+    if (n > kMaxPathsPerBatch) { rt_set_error("probe: at most %u rays per call", kMaxPathsPerBatch); return RT_ERR_INVALID; }
+    int rc = ensure_work(s, n, 2);
+    if (rc != RT_OK) return rc;
+    rt_camera cam;
+    std::memset(&cam, 0, sizeof cam);
+    cam.width = n;
+    cam.height = 1;
+    Frame f = make_frame(&cam, opt);
+    f.n_paths = n;
+    float *d_a = nullptr, *d_b = nullptr, *d_t = nullptr, *d_abg = nullptr;
+    int32_t *d_s = nullptr, *d_tr = nullptr, *d_v = nullptr;
+    std::vector<void*> tmp;
+    auto grab = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) tmp.push_back(*p); return e; };
+    auto release = [&]() { for (void* p : tmp) (void)hipFree(p); };
+    hipError_t e = hipSuccess;
+    if ((e = grab((void**)&d_a, 3 * (size_t)n * 4)) || (e = grab((void**)&d_b, 3 * (size_t)n * 4)) || (e = grab((void**)&d_t, (size_t)n * 4)) ||
+        (e = grab((void**)&d_abg, 3 * (size_t)n * 4)) || (e = grab((void**)&d_s, (size_t)n * 4)) || (e = grab((void**)&d_tr, (size_t)n * 4)) ||
+        (e = grab((void**)&d_v, (size_t)n * 4))) {
+        release();
+        rt_set_error("probe: hipMalloc failed: %s", hipGetErrorString(e));
+        return RT_ERR_NOMEM;
+    }
+    const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+    rc = RT_OK;
+    do {
+        if (hipMemcpy(d_a, a, 3 * (size_t)n * 4, hipMemcpyHostToDevice) || hipMemcpy(d_b, b, 3 * (size_t)n * 4, hipMemcpyHostToDevice) ||
+            hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(s->w.q_count, 0, 2 * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, s->w, f, (const float*)d_a, (const float*)d_b, as_segments);
+        if (launch_mesh(s, 0, nullptr, false) != RT_OK) { rc = RT_ERR_DEVICE; break; }
+        hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, s->w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }
+        if (as_segments) {
+            if (hipMemcpy(out_visible, d_v, (size_t)n * 4, hipMemcpyDeviceToHost)) rc = RT_ERR_DEVICE;
+        } else {
+            std::vector<float> abg(3 * (size_t)n);
+            std::vector<int32_t> tri(n);
+            if (hipMemcpy(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost) || hipMemcpy(out_sphere, d_s, (size_t)n * 4, hipMemcpyDeviceToHost) ||
+                hipMemcpy(tri.data(), d_tr, (size_t)n * 4, hipMemcpyDeviceToHost) || hipMemcpy(abg.data(), d_abg, 3 * (size_t)n * 4, hipMemcpyDeviceToHost)) {
+                rc = RT_ERR_DEVICE;
+                break;
+            }
+            for (uint32_t i = 0; i < n; i++) {
+                out_triangle[i] = tri[i];
+                if (tri[i] >= 0 && out_abg) { out_abg[3 * i] = abg[3 * i]; out_abg[3 * i + 1] = abg[3 * i + 1]; out_abg[3 * i + 2] = abg[3 * i + 2]; }
+            }
+        }
+    } while (0);
+    if (rc != RT_OK) rt_set_error("probe: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+    release();
+    return rc;
+}
+
+} // namespace
+
+extern "C" int rt_cast(rt_scene* s, const rt_options* opt, uint32_t n, const float* origins, const float* dirs, float* out_t,
+                       int32_t* out_sphere, int32_t* out_triangle, float* out_abg) {
+    if (n && (!out_t || !out_sphere || !out_triangle)) { rt_set_error("rt_cast: null output"); return RT_ERR_INVALID; }
+    return probe(s, opt, n, origins, dirs, 0, out_t, out_sphere, out_triangle, out_abg, nullptr);
+}
+
+extern "C" int rt_visible(rt_scene* s, const rt_options* opt, uint32_t n, const float* origins, const float* targets,
+                          int32_t* out_visible) {
+    if (n && !out_visible) { rt_set_error("rt_visible: null output"); return RT_ERR_INVALID; }
+    return probe(s, opt, n, origins, targets, 1, nullptr, nullptr, nullptr, nullptr, out_visible);
+}

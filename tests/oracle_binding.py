@@ -1,0 +1,136 @@
+"""ctypes binding of oracle/libpathtrace_oracle.so (test infrastructure only).
+
+The oracle's structs are declared independently in oracle/pathtrace_oracle.h;
+their layout is the same as the product's rt_scene_desc / rt_camera, so the
+ctypes classes of ``raytracer_amd`` are reused for them.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+import raytracer_amd as rt
+
+ORACLE_DIR = os.path.join(rt.REPO_ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libpathtrace_oracle.so")
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+
+
+class OrcOptions(C.Structure):
+    _fields_ = [("indirect", C.c_int32), ("antialiasing", C.c_int32), ("bounding_box", C.c_int32),
+                ("max_depth", C.c_int32), ("seed", C.c_uint32), ("use_libm", C.c_int32)]
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("paths", "bounce_iterations", "casts", "sphere_tests", "box_tests",
+                                          "mesh_walks", "triangle_tests", "uniforms")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def _load():
+    if not os.path.exists(ORACLE_LIB):
+        raise ImportError(f"{ORACLE_LIB} missing: run `make -C oracle`")
+    lib = C.CDLL(ORACLE_LIB)
+    lib.orc_render_pixels.argtypes = [C.POINTER(rt.SceneDesc), C.POINTER(rt.Camera), C.POINTER(OrcOptions), _u32p,
+                                      C.c_uint32, C.c_uint32, C.c_uint32, _f32p, _f32p, _u32p,
+                                      C.POINTER(OrcCounters), C.c_int32]
+    lib.orc_cast.argtypes = [C.POINTER(rt.SceneDesc), C.POINTER(OrcOptions), C.c_uint32, _f32p, _f32p, _f32p, _i32p,
+                             _i32p, _f32p]
+    lib.orc_visible.argtypes = [C.POINTER(rt.SceneDesc), C.POINTER(OrcOptions), C.c_uint32, _f32p, _f32p, _i32p]
+    lib.orc_random_cos.argtypes = [C.c_uint32, _f32p, _f32p, _f32p, C.c_int32, _f32p]
+    lib.orc_primary_ray.argtypes = [C.POINTER(rt.Camera), C.POINTER(OrcOptions), C.c_uint32, C.c_uint32, _f32p, _u32p]
+    lib.orc_uniforms.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
+    for n in ("orc_render_pixels", "orc_cast", "orc_visible", "orc_random_cos", "orc_primary_ray", "orc_uniforms"):
+        getattr(lib, n).restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, use_libm=False):
+    return OrcOptions(int(indirect), int(antialiasing), int(bounding_box), int(max_depth), int(seed) & 0xFFFFFFFF,
+                      int(use_libm))
+
+
+def from_rt_options(o: rt.Options, use_libm=False):
+    return OrcOptions(o.indirect, o.antialiasing, o.bounding_box, o.max_depth, o.seed, int(use_libm))
+
+
+def render_pixels(desc, cam, opt, pixels, sample_begin=0, sample_end=None, threads=0):
+    """Returns (rgb[n,3], sum[n,3], count[n], counters dict)."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint32)
+    n = len(px)
+    if sample_end is None:
+        sample_end = cam.num_rays
+    rgb = np.empty((n, 3), np.float32)
+    ssum = np.empty((n, 3), np.float32)
+    cnt = np.empty(n, np.uint32)
+    counters = OrcCounters()
+    rc = lib.orc_render_pixels(C.byref(desc), C.byref(cam), C.byref(opt), px.ctypes.data_as(_u32p), n, sample_begin,
+                               sample_end, rgb.ctypes.data_as(_f32p), ssum.ctypes.data_as(_f32p),
+                               cnt.ctypes.data_as(_u32p), C.byref(counters), threads)
+    assert rc == 0, "orc_render_pixels failed"
+    return rgb, ssum, cnt, counters.as_dict()
+
+
+def render_image(desc, cam, opt, threads=0):
+    n = cam.width * cam.height
+    rgb, _, _, counters = render_pixels(desc, cam, opt, np.arange(n, dtype=np.uint32), threads=threads)
+    return rgb.reshape(cam.height, cam.width, 3), counters
+
+
+def cast(desc, opt, origins, dirs):
+    o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    n = len(o)
+    t = np.empty(n, np.float32)
+    sid = np.empty(n, np.int32)
+    tid = np.empty(n, np.int32)
+    abg = np.zeros((n, 3), np.float32)
+    rc = lib.orc_cast(C.byref(desc), C.byref(opt), n, o.ctypes.data_as(_f32p), d.ctypes.data_as(_f32p),
+                      t.ctypes.data_as(_f32p), sid.ctypes.data_as(_i32p), tid.ctypes.data_as(_i32p),
+                      abg.ctypes.data_as(_f32p))
+    assert rc == 0
+    return t, sid, tid, abg
+
+
+def visible(desc, opt, origins, targets):
+    o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(targets, np.float32).reshape(-1, 3)
+    vis = np.empty(len(o), np.int32)
+    rc = lib.orc_visible(C.byref(desc), C.byref(opt), len(o), o.ctypes.data_as(_f32p), d.ctypes.data_as(_f32p),
+                         vis.ctypes.data_as(_i32p))
+    assert rc == 0
+    return vis
+
+
+def random_cos(normals, r1, r2, use_libm=False):
+    nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    a = np.ascontiguousarray(r1, np.float32)
+    b = np.ascontiguousarray(r2, np.float32)
+    out = np.empty_like(nrm)
+    rc = lib.orc_random_cos(len(nrm), nrm.ctypes.data_as(_f32p), a.ctypes.data_as(_f32p), b.ctypes.data_as(_f32p),
+                            int(use_libm), out.ctypes.data_as(_f32p))
+    assert rc == 0
+    return out
+
+
+def primary_ray(cam, opt, pixel, sample):
+    out = np.empty(3, np.float32)
+    dims = C.c_uint32()
+    rc = lib.orc_primary_ray(C.byref(cam), C.byref(opt), pixel, sample, out.ctypes.data_as(_f32p), C.byref(dims))
+    assert rc == 0
+    return out, dims.value
+
+
+def uniforms(seed, pixel, sample, first_dim, n):
+    out = np.empty(n, np.float32)
+    rc = lib.orc_uniforms(seed, pixel, sample, first_dim, n, out.ctypes.data_as(_f32p))
+    assert rc == 0
+    return out
