@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one frame of the workload the headline metric is quoted on: the cat
+mesh scene (assets/scenes/mesh_scene.json, 3 954 triangles) at 512x512, 32
+samples per pixel, 5 bounces, indirect lighting + anti-aliasing + bounding box.
+The scene is resident in HBM before the timed region; every step renders the
+whole frame.  With N > 1 (one process per GPU, launched by torch.distributed.run)
+the 32 samples of every pixel are split over the ranks, each rank accumulates
+linear radiance for its sample range, the buffers are summed with one RCCL
+all-reduce and every rank resolves the image: total work is fixed (strong
+scaling).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic work per test of the reference formulation: 47 flop per
+# ray-triangle test (3 vector subtractions, 2 cross products, 3 dot products,
+# 2 divisions, 1 negation, 2 subtractions; reference src/raytrace.cu:155-164).
+FLOP_PER_TRIANGLE_TEST = 47
+PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X fp32 vector peak (packed FMA)
+# the reference's published time for this configuration: 53.77 s on a GTX 1050
+# (reference README.md:78) = 512*512*32 / 53.77 paths per second
+BASELINE_MPATHS = 512 * 512 * 32 / 53.77 / 1e6
+
+
+def sample_range(rank, world, spp):
+    base, extra = divmod(spp, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def cpu_baseline(desc, cam, opt, n_pixels_sample=65536):
+    """Times the CPU oracle on a bounded sample of the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    rng = np.random.default_rng(1234)
+    pixels = rng.choice(cam.width * cam.height, size=n_pixels_sample, replace=False).astype(np.uint32)
+    oopt = ob.from_rt_options(opt)
+    t0 = time.perf_counter()
+    _, _, _, counters = ob.render_pixels(desc, cam, oopt, pixels, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": counters["paths"] / dt / 1e6,
+        "unit": "Mpaths/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_pixels_sample} random pixels x {cam.num_rays} spp of the same frame "
+                  f"({counters['paths']} paths, {dt:.1f} s, {counters['triangle_tests'] / counters['paths']:.0f} "
+                  f"triangle tests/path)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="mesh_scene")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import raytracer_amd as rt
+
+    rt.init(local_rank)
+    scene = rt.Scene()
+    scene.load_scene(os.path.join(rt.ASSETS, "scenes", args.scene + ".json"))
+    desc, cam = scene.describe()
+    dev = scene.upload()
+    opt = rt.make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, profile=True)
+    n_pixels = cam.width * cam.height
+    spp = cam.num_rays
+    s_begin, s_end = sample_range(rank, world, spp)
+
+    d_sum = torch.zeros(n_pixels * 4, dtype=torch.float32, device="cuda")
+    d_img = torch.empty(n_pixels * 3, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    mesh_ms = 0.0
+    mesh_launches = 0
+    tri_tests = 0
+
+    def step(timed):
+        nonlocal mesh_ms, mesh_launches, tri_tests
+        d_sum.zero_()
+        st = dev.accumulate(cam, opt, s_begin, s_end, d_sum.data_ptr(), stream, want_stats=True)
+        if world > 1:
+            dist.all_reduce(d_sum)
+        rt.resolve(d_sum.data_ptr(), n_pixels, d_img.data_ptr(), stream)
+        if timed:
+            mesh_ms += st.mesh_kernel_ms
+            mesh_launches += st.mesh_kernel_launches
+            tri_tests += st.triangle_tests
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_pixels * spp / (elapsed / args.steps) / 1e6
+        # dominant kernel: k_mesh.  Algorithmic flops of the launches of rank 0
+        # (47 per ray-triangle test the kernel executed) over their summed
+        # duration, measured with HIP events on the launch stream.
+        achieved = (tri_tests * FLOP_PER_TRIANGLE_TEST) / (mesh_ms * 1e-3) / 1e12 if mesh_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "mesh_kernel_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "Mpaths/s, cat mesh 512x512 32spp 5-bounce indirect+AA+bbox",
+            "value": value,
+            "unit": "Mpaths/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "s_per_frame": ms_per_step / 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": value / BASELINE_MPATHS,
+            "dtype": "f32",
+            "data": "synthetic scene file shipped with the repo (mesh_scene.json + cat.obj), fixed seed",
+            "config": {
+                "workload": f"{args.scene}.json {cam.width}x{cam.height} {spp}spp depth5 indirect+AA+bbox",
+                "triangles": int(desc.n_triangles),
+                "parallelism": f"spp-split x{world} + RCCL all-reduce of linear radiance" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "valu",
+                "kernel": "k_mesh",
+                "achieved": achieved,
+                "peak": PEAK_FP32_VECTOR_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                "traffic": traffic,
+                "avg_launch_ms": mesh_ms / mesh_launches if mesh_launches else None,
+                "launches_per_step": mesh_launches / args.steps,
+                "triangle_tests_per_step": tri_tests / args.steps,
+                "kernel_share_of_step": mesh_ms / (elapsed * 1e3),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(desc, cam, opt)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
