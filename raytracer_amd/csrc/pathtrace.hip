@@ -58,8 +58,10 @@ extern "C" const char* rt_last_error(void) { return g_error; }
 namespace {
 
 constexpr uint32_t kBlock = 256;            // threads per workgroup (4 wavefronts)
-constexpr uint32_t kMeshChunk = 512;        // triangles per k_mesh job
+constexpr uint32_t kWavesPerBlock = kBlock / 64;
+constexpr uint32_t kChunkPairs = 256;       // triangle pairs per k_mesh job (512 triangles)
 constexpr uint32_t kMeshGrid = 256 * 8;     // persistent k_mesh grid: 8 workgroups per CU
+constexpr uint32_t kShards = 64;            // ray-queue shards = lanes of a wavefront
 constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none)
 constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
 constexpr uint32_t kMaxLights = 64;
@@ -79,6 +81,8 @@ struct DeviceScene {
     const float4* mat_color;  // colour.xyz, type as int bits
     const float2* mat_ior;    // ro, ri
     const float4* tri_geom;   // 3 per triangle: A.xyz e1.x | e1.yz e2.xy | e2.z N.xyz
+    const float2* tri_pair;   // 12 per PAIR of triangles (2j, 2j+1): A.x A.y A.z e1.xyz e2.xyz N.xyz,
+                              // each as (value of 2j, value of 2j+1); k_mesh streams this one
     const float4* tri_shade;  // 3 per triangle: n0.xyz material | n1.xyz - | n2.xyz -
     const float4* box_min;
     const float4* box_max;
@@ -96,7 +100,8 @@ struct Work {
     unsigned long long* hit; // paths + paths*n_lights slots: (t bits << 32) | triangle
     float4* q_o;     // queued ray origin.xyz, hit slot as uint bits
     float4* q_d;     // queued ray direction.xyz
-    uint32_t* q_count; // one counter per k_mesh launch of a batch
+    uint32_t* q_count; // kShards counters per k_mesh launch of a batch
+    uint32_t shard_capacity; // queue entries reserved per shard
 };
 
 struct V3 {
@@ -190,17 +195,21 @@ __device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, V3 ray, V3 st
 }
 
 // Appends the rays of the lanes with want == true to the k_mesh queue: one
-// atomic per wavefront, slots in lane order.
+// atomic per wavefront, slots in lane order.  The queue is split into kShards
+// shards with a counter each and a wavefront always uses the shard of its own
+// index, which spreads the returning atomics over 64 addresses (one address
+// serialises at well under 200 atomics per microsecond).
 __device__ __forceinline__ void enqueue(const Work& w, uint32_t counter, bool want, V3 start, V3 ray, uint32_t slot) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0) return;
     const uint32_t lane = __lane_id();
+    const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
     const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&w.q_count[counter], (uint32_t)__popcll(mask));
+    if (lane == leader) base = atomicAdd(&w.q_count[counter * kShards + shard], (uint32_t)__popcll(mask));
     base = __shfl(base, (int)leader);
     if (want) {
-        const uint32_t at = base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
+        const size_t at = (size_t)shard * w.shard_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
         w.q_o[at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot));
         w.q_d[at] = make_float4(ray.x, ray.y, ray.z, 0.f);
     }
@@ -228,64 +237,109 @@ __device__ __forceinline__ void barycentrics(const DeviceScene& sc, int tri, V3 
 
 // ------------------------------------------------------------- k_mesh
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Exact tail of one ray-triangle test (reference src/raytrace.cu:161-174),
+// entered only by lanes the division-free test could not reject.
+__device__ __forceinline__ void exact_hit(float nb, float ng, float d, float ao_dot_n, uint32_t index, float& best, int& best_i) {
+    const float beta = nb / d;
+    const float gamma = -ng / d;
+    const float alpha = 1.f - beta - gamma;
+    if (alpha >= 0 && beta >= 0 && gamma >= 0) {
+        const float t = ao_dot_n / d;
+        if (t > 0 && (best_i < 0 || t < best)) { best = t; best_i = (int)index; }
+    }
+}
+
 // Every queued ray against every triangle (reference src/raytrace.cu:148-175).
-// A job is 256 rays x one chunk of triangles; the nearest hit per ray is
-// merged across chunks with a 64-bit atomic minimum on (t bits, triangle),
-// which orders by distance first and by triangle index second, i.e. the
-// reference's "first triangle wins ties" rule.
 //
-// Per triangle a lane first evaluates the reference's numerators and
-// denominator (bit-identical values) and a division-free test with an
-// approximate reciprocal; only lanes that may be inside the triangle take the
-// exact path with the reference's three IEEE divisions.  A reference-accepted
-// hit has alpha, beta, gamma in [0, 1], where the approximate values are off
-// by < 1e-6, so the 1e-5 margin never drops one; a NaN passes the test.
-__global__ __launch_bounds__(kBlock) void k_mesh(const float4* __restrict__ tri, uint32_t n_tri,
+// A lane owns a ray; the triangle index is wave-uniform, so triangle data
+// arrives by scalar loads and stays in SGPRs.  Two triangles are tested per
+// iteration with packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 work on
+// a register pair at the issue cost of one instruction): tri_pair holds every
+// quantity as (triangle 2j, triangle 2j+1), the ray components are broadcast.
+//
+// Per triangle a lane evaluates the reference's numerators e2.q, e1.q and
+// denominator u.N with the reference's operation order (bit-identical values)
+// and then a division-free test with an approximate reciprocal.  Only lanes
+// that may be inside a triangle take exact_hit with the reference's three IEEE
+// divisions.  A reference-accepted hit has alpha, beta, gamma in [0, 1], where
+// the approximate values are off by < 1e-6, so the 1e-5 margin never drops
+// one; a NaN passes the test.
+//
+// A job is 256 rays x one chunk of triangle pairs.  The nearest hit per ray is
+// merged across chunks with a 64-bit atomic minimum on (t bits, triangle),
+// which orders by distance first and triangle index second: the reference's
+// "first triangle wins ties".  Jobs are dealt so that the chunks of one ray
+// block run on workgroups with equal blockIdx % 8, which share an L2.
+__global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, uint32_t n_tri,
                                                  const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                 const uint32_t* __restrict__ q_count,
+                                                 const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
                                                  unsigned long long* __restrict__ hit) {
-    const uint32_t count = *q_count;
-    const uint32_t n_chunks = (n_tri + kMeshChunk - 1) / kMeshChunk;
-    const uint32_t n_jobs = ((count + kBlock - 1) / kBlock) * n_chunks;
-    for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
-        const uint32_t ray_block = job / n_chunks;
-        const uint32_t chunk = job - ray_block * n_chunks;
-        const uint32_t r = ray_block * kBlock + threadIdx.x;
+    // lane l of every wavefront holds shard l's ray count and the number of
+    // 256-ray blocks in the shards before it
+    const uint32_t lane = __lane_id();
+    const uint32_t my_count = q_count[lane];
+    const uint32_t my_blocks = (my_count + kBlock - 1) / kBlock;
+    uint32_t incl = my_blocks;
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) {
+        const uint32_t up = __shfl_up(incl, step);
+        if ((int)lane >= step) incl += up;
+    }
+    const uint32_t before = incl - my_blocks;
+    const uint32_t n_ray_blocks = __shfl(incl, 63);
+    if (n_ray_blocks == 0) return;
+
+    const uint32_t n_pairs = (n_tri + 1) / 2;
+    const uint32_t n_chunks = (n_pairs + kChunkPairs - 1) / kChunkPairs;
+    const uint32_t xcd = blockIdx.x % 8;
+    const uint32_t per_xcd = ((n_ray_blocks + 7) / 8) * n_chunks;
+    for (uint32_t q = blockIdx.x / 8; q < per_xcd; q += gridDim.x / 8) {
+        const uint32_t ray_block = (q / n_chunks) * 8 + xcd;
+        if (ray_block >= n_ray_blocks) continue;
+        const uint32_t chunk = q % n_chunks;
+        // shard that holds this ray block: the last one whose prefix is <= it
+        const uint32_t shard = (uint32_t)__popcll(__ballot(before <= ray_block)) - 1u; // `before` is non-decreasing
+        const uint32_t shard_first = __shfl(before, (int)shard);
+        const uint32_t count = __shfl(my_count, (int)shard);
+        const uint32_t r = (ray_block - shard_first) * kBlock + threadIdx.x;
         const bool active = r < count;
-        const uint32_t rr = active ? r : count - 1; // idle lanes shadow a real ray
-        const float4 o4 = q_o[rr];
-        const float4 d4 = q_d[rr];
+        const size_t at = (size_t)shard * shard_capacity + (active ? r : count - 1); // idle lanes shadow a real ray
+        const float4 o4 = q_o[at];
+        const float4 d4 = q_d[at];
         const float ox = o4.x, oy = o4.y, oz = o4.z;
         const float ux = d4.x, uy = d4.y, uz = d4.z;
         float best = INFINITY;
         int best_i = -1;
-        const uint32_t first = chunk * kMeshChunk;
-        const uint32_t last = min(first + kMeshChunk, n_tri);
+        const uint32_t first = chunk * kChunkPairs;
+        const uint32_t last = min(first + kChunkPairs, n_pairs);
 #pragma unroll 2
-        for (uint32_t i = first; i < last; i++) {
-            const float4 g0 = tri[3 * i + 0];
-            const float4 g1 = tri[3 * i + 1];
-            const float4 g2 = tri[3 * i + 2];
-            const float aox = g0.x - ox, aoy = g0.y - oy, aoz = g0.z - oz;
-            const float qx = aoy * uz - aoz * uy;
-            const float qy = aoz * ux - aox * uz;
-            const float qz = aox * uy - aoy * ux;
-            const float d = (ux * g2.y + uy * g2.z) + uz * g2.w;
-            const float nb = (g1.z * qx + g1.w * qy) + g2.x * qz; // e2 . q
-            const float ng = (g0.w * qx + g1.x * qy) + g1.y * qz; // e1 . q
-            const float rcp = __builtin_amdgcn_rcpf(d);
-            const float b_ = nb * rcp;
-            const float g_ = -ng * rcp;
-            const float a_ = (1.f - b_) - g_;
-            const float lo = fminf(fminf(a_, b_), g_);
-            if (!(lo < -1e-5f)) {
-                const float beta = nb / d;
-                const float gamma = -ng / d;
-                const float alpha = 1.f - beta - gamma;
-                if (alpha >= 0 && beta >= 0 && gamma >= 0) {
-                    const float t = ((aox * g2.y + aoy * g2.z) + aoz * g2.w) / d;
-                    if (t > 0 && (best_i < 0 || t < best)) { best = t; best_i = (int)i; }
-                }
+        for (uint32_t j = first; j < last; j++) {
+            const f2* __restrict__ g = tri2 + 12 * (size_t)j;
+            const f2 Ax = g[0], Ay = g[1], Az = g[2];
+            const f2 e1x = g[3], e1y = g[4], e1z = g[5];
+            const f2 e2x = g[6], e2y = g[7], e2z = g[8];
+            const f2 Nx = g[9], Ny = g[10], Nz = g[11];
+            const f2 aox = Ax - ox, aoy = Ay - oy, aoz = Az - oz;
+            const f2 qx = aoy * uz - aoz * uy;
+            const f2 qy = aoz * ux - aox * uz;
+            const f2 qz = aox * uy - aoy * ux;
+            const f2 d = (ux * Nx + uy * Ny) + uz * Nz;
+            const f2 nb = (e2x * qx + e2y * qy) + e2z * qz; // e2 . q
+            const f2 ng = (e1x * qx + e1y * qy) + e1z * qz; // e1 . q
+            f2 rcp;
+            rcp.x = __builtin_amdgcn_rcpf(d.x);
+            rcp.y = __builtin_amdgcn_rcpf(d.y);
+            const f2 b_ = nb * rcp;
+            const f2 g_ = -ng * rcp;
+            const f2 a_ = (1.f - b_) - g_;
+            const float lo0 = fminf(fminf(a_.x, b_.x), g_.x);
+            const float lo1 = fminf(fminf(a_.y, b_.y), g_.y);
+            if (!(lo0 < -1e-5f) || !(lo1 < -1e-5f)) {
+                const f2 aon = (aox * Nx + aoy * Ny) + aoz * Nz;
+                if (!(lo0 < -1e-5f)) exact_hit(nb.x, ng.x, d.x, aon.x, 2 * j, best, best_i);
+                if (!(lo1 < -1e-5f)) exact_hit(nb.y, ng.y, d.y, aon.y, 2 * j + 1, best, best_i);
             }
         }
         if (active && best_i >= 0) {
@@ -756,15 +810,21 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     free_work(s);
     const size_t nl = s->d.n_lights ? s->d.n_lights : 1;
     const size_t slots = (size_t)n_paths * (1 + nl);
+    // a shard receives the rays of every kShards-th wavefront of a path kernel
+    const size_t n_waves = (((size_t)n_paths + kBlock - 1) / kBlock) * kWavesPerBlock;
+    const size_t shard_capacity = ((n_waves + kShards - 1) / kShards) * 64 * (1 + nl);
+    const size_t queue_entries = shard_capacity * kShards;
+    if (shard_capacity > 0xffffffffu) { rt_set_error("batch too large for the ray queue"); return RT_ERR_INVALID; }
     int rc;
     if ((rc = work_alloc(s, &s->w.ray_o, n_paths)) || (rc = work_alloc(s, &s->w.ray_d, n_paths)) ||
         (rc = work_alloc(s, &s->w.thr, n_paths)) || (rc = work_alloc(s, &s->w.rad, n_paths)) ||
         (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
-        (rc = work_alloc(s, &s->w.q_o, slots)) || (rc = work_alloc(s, &s->w.q_d, slots)) ||
-        (rc = work_alloc(s, &s->w.q_count, n_counters))) {
+        (rc = work_alloc(s, &s->w.q_o, queue_entries)) || (rc = work_alloc(s, &s->w.q_d, queue_entries)) ||
+        (rc = work_alloc(s, &s->w.q_count, (size_t)n_counters * kShards))) {
         free_work(s);
         return rc;
     }
+    s->w.shard_capacity = (uint32_t)shard_capacity;
     s->work_paths = n_paths;
     s->n_counters = n_counters;
     return RT_OK;
@@ -797,8 +857,9 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile)
         s->events.push_back(e1);
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    hipLaunchKernelGGL(k_mesh, dim3(kMeshGrid), dim3(kBlock), 0, stream, s->d.tri_geom, s->d.n_triangles,
-                       (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)(s->w.q_count + counter), s->w.hit);
+    hipLaunchKernelGGL(k_mesh, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.tri_pair),
+                       s->d.n_triangles, (const float4*)s->w.q_o, (const float4*)s->w.q_d,
+                       (const uint32_t*)(s->w.q_count + (size_t)counter * kShards), s->w.shard_capacity, s->w.hit);
     HIP_TRY(hipGetLastError());
     if (profile) HIP_TRY(hipEventRecord(e1, stream));
     return RT_OK;
@@ -854,6 +915,19 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
             shade[3 * i + k] = make_float4(n[0], n[1], n[2], k == 0 ? mat_bits : 0.f);
         }
     }
+    // the same twelve numbers per triangle, interleaved two triangles at a time
+    // for the packed-fp32 inner loop; an odd count is padded with an all-zero
+    // triangle, whose zero denominator can never produce a hit
+    const size_t n_pairs = ((size_t)d->n_triangles + 1) / 2;
+    std::vector<float2> pair(12 * n_pairs, make_float2(0.f, 0.f));
+    for (uint32_t i = 0; i < d->n_triangles; i++) {
+        const float4 g0 = geom[3 * i + 0], g1 = geom[3 * i + 1], g2 = geom[3 * i + 2];
+        const float v[12] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w};
+        for (int k = 0; k < 12; k++) {
+            float2& dst = pair[12 * (size_t)(i / 2) + k];
+            if (i & 1) dst.y = v[k]; else dst.x = v[k];
+        }
+    }
     std::vector<float4> box_min(d->n_boxes), box_max(d->n_boxes), light(d->n_lights);
     for (uint32_t i = 0; i < d->n_boxes; i++) {
         box_min[i] = make_float4(d->box_min[3 * i], d->box_min[3 * i + 1], d->box_min[3 * i + 2], 0.f);
@@ -869,7 +943,7 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     s->d.n_lights = d->n_lights;
     if ((rc = upload(s, sphere, &s->d.sphere)) || (rc = upload(s, sphere_mat, &s->d.sphere_mat)) ||
         (rc = upload(s, mat_color, &s->d.mat_color)) || (rc = upload(s, mat_ior, &s->d.mat_ior)) ||
-        (rc = upload(s, geom, &s->d.tri_geom)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
+        (rc = upload(s, geom, &s->d.tri_geom)) || (rc = upload(s, pair, &s->d.tri_pair)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
         (rc = upload(s, box_min, &s->d.box_min)) || (rc = upload(s, box_max, &s->d.box_max)) ||
         (rc = upload(s, light, &s->d.light))) {
         rt_scene_free(s);
@@ -915,7 +989,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         HIP_TRY(hipEventCreate(&t1));
         HIP_TRY(hipEventRecord(t0, stream));
     }
-    std::vector<uint32_t> counts(n_counters);
+    std::vector<uint32_t> counts((size_t)n_counters * kShards);
     uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
     uint32_t batches = 0;
 
@@ -924,7 +998,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         f.n_paths = in_batch * n_pixels;
         f.sample_begin = sample_begin + first;
         const dim3 grid((f.n_paths + kBlock - 1) / kBlock), block(kBlock);
-        HIP_TRY(hipMemsetAsync(s->w.q_count, 0, n_counters * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(s->w.q_count, 0, counts.size() * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_generate, grid, block, 0, stream, s->d, s->w, f);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
@@ -939,9 +1013,9 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         batches++;
         paths += f.n_paths;
         if (stats) { // the counters are reused by the next batch: read them now
-            HIP_TRY(hipMemcpyAsync(counts.data(), s->w.q_count, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(counts.data(), s->w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            for (uint32_t c = 0; c < n_counters; c++) mesh_rays += counts[c];
+            for (uint32_t c : counts) mesh_rays += c;
         }
     }
     if (stats) {
@@ -1033,7 +1107,7 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
     rc = RT_OK;
     do {
         if (hipMemcpy(d_a, a, 3 * (size_t)n * 4, hipMemcpyHostToDevice) || hipMemcpy(d_b, b, 3 * (size_t)n * 4, hipMemcpyHostToDevice) ||
-            hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(s->w.q_count, 0, 2 * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+            hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(s->w.q_count, 0, 2 * kShards * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, s->w, f, (const float*)d_a, (const float*)d_b, as_segments);
         if (launch_mesh(s, 0, nullptr, false) != RT_OK) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, s->w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
