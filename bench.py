@@ -34,12 +34,6 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X fp32 vector peak (packed FMA)
 BASELINE_MPATHS = 512 * 512 * 32 / 53.77 / 1e6
 
 
-def sample_range(rank, world, spp):
-    base, extra = divmod(spp, world)
-    begin = rank * base + min(rank, extra)
-    return begin, begin + base + (1 if rank < extra else 0)
-
-
 def cpu_baseline(desc, cam, opt, n_pixels_sample=65536):
     """Times the CPU oracle on a bounded sample of the same frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -94,11 +88,10 @@ def main():
     opt = rt.make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, profile=True)
     n_pixels = cam.width * cam.height
     spp = cam.num_rays
-    s_begin, s_end = sample_range(rank, world, spp)
 
-    d_sum = torch.zeros(n_pixels * 4, dtype=torch.float32, device="cuda")
-    d_img = torch.empty(n_pixels * 3, dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    from raytracer_amd.distributed import FrameRenderer
+
+    renderer = FrameRenderer(dev, cam, opt, want_stats=True)
 
     mesh_ms = 0.0
     mesh_launches = 0
@@ -106,12 +99,9 @@ def main():
 
     def step(timed):
         nonlocal mesh_ms, mesh_launches, tri_tests
-        d_sum.zero_()
-        st = dev.accumulate(cam, opt, s_begin, s_end, d_sum.data_ptr(), stream, want_stats=True)
-        if world > 1:
-            dist.all_reduce(d_sum)
-        rt.resolve(d_sum.data_ptr(), n_pixels, d_img.data_ptr(), stream)
-        if timed:
+        renderer.render()
+        st = renderer.last_stats
+        if timed and st is not None:
             mesh_ms += st.mesh_kernel_ms
             mesh_launches += st.mesh_kernel_launches
             tri_tests += st.triangle_tests

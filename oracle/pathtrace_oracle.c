@@ -469,3 +469,17 @@ int orc_uniforms(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first_
     for (uint32_t i = 0; i < n; i++) out[i] = rt_rng_uniform(k, first_dim + i);
     return 0;
 }
+
+int orc_math_probe(int32_t kind, uint32_t n, const float* in, float* out) {
+    for (uint32_t i = 0; i < n; i++) {
+        float s, c;
+        switch (kind) {
+            case 0: out[i] = rt_logf(in[i]); break;
+            case 1: rt_sincosf(in[i], &s, &c); out[i] = s; break;
+            case 2: rt_sincosf(in[i], &s, &c); out[i] = c; break;
+            case 3: out[i] = rt_gamma_encode(in[i]); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}

@@ -126,6 +126,10 @@ int orc_primary_ray(const orc_camera* cam, const orc_options* opt, uint32_t pixe
 int orc_uniforms(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first_dim,
                  uint32_t n, float* out);
 
+/* The fixed polynomial kernels of rt_math.h, for accuracy tests:
+ * kind 0 = log, 1 = sin, 2 = cos, 3 = output transfer curve x^(1/2.2). */
+int orc_math_probe(int32_t kind, uint32_t n, const float* in, float* out);
+
 #ifdef __cplusplus
 }
 #endif

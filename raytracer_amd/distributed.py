@@ -1,0 +1,83 @@
+"""Multi-GPU frame driver: one process per GPU, samples split over ranks.
+
+The reference renders on one GPU.  Its sample loop (reference
+src/raytrace.cu:478-500) is embarrassingly parallel once every sample owns its
+random stream, and its only coupling is the per-pixel mean followed by the
+non-linear gamma curve.  So every rank renders a contiguous range of the
+GLOBAL sample indices of every pixel into a linear (r, g, b, actual_rays)
+buffer, the buffers are summed with ONE all-reduce (RCCL over xGMI when the
+process group is "nccl"), and the mean + gamma run once on the summed buffer.
+The image does not depend on the number of ranks except for the order of the
+fp32 additions across rank boundaries.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+
+def sample_range(rank: int, world: int, spp: int) -> Tuple[int, int]:
+    """Contiguous share [begin, end) of samples 0..spp-1 for `rank` of `world`.
+
+    Shares differ by at most one sample; ranks beyond spp get an empty range.
+    """
+    if world <= 0 or not 0 <= rank < world or spp < 0:
+        raise ValueError(f"bad partition request rank={rank} world={world} spp={spp}")
+    base, extra = divmod(spp, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+class FrameRenderer:
+    """Renders whole frames of one scene with the samples split over a process group.
+
+    accumulate(cam, opt, s_begin, s_end, sum_tensor) must ADD the linear colour
+    sums and sample counts of the sample range into sum_tensor (4 floats per
+    pixel); resolve(sum_tensor, out_tensor) must write gamma(mean).  The
+    defaults call the HIP library on the current CUDA stream; the CPU test
+    suite injects host implementations to exercise the partition + reduction
+    logic under the gloo backend.
+    """
+
+    def __init__(self, dev, cam, opt, *, group=None, tensor_device="cuda",
+                 accumulate: Optional[Callable] = None, resolve: Optional[Callable] = None,
+                 want_stats: bool = False):
+        import torch
+        import torch.distributed as dist
+
+        self.torch = torch
+        self.dist = dist
+        self.dev, self.cam, self.opt = dev, cam, opt
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.n_pixels = cam.width * cam.height
+        self.s_begin, self.s_end = sample_range(self.rank, self.world, cam.num_rays)
+        self.sum = torch.zeros(self.n_pixels * 4, dtype=torch.float32, device=tensor_device)
+        self.image = torch.empty(self.n_pixels * 3, dtype=torch.float32, device=tensor_device)
+        self.want_stats = want_stats
+        self.last_stats = None
+        self._accumulate = accumulate or self._hip_accumulate
+        self._resolve = resolve or self._hip_resolve
+
+    def _stream(self) -> int:
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def _hip_accumulate(self, cam, opt, s_begin, s_end, sum_tensor):
+        self.last_stats = self.dev.accumulate(cam, opt, s_begin, s_end, sum_tensor.data_ptr(), self._stream(),
+                                              want_stats=self.want_stats)
+
+    def _hip_resolve(self, sum_tensor, out_tensor):
+        import raytracer_amd as rt
+
+        rt.resolve(sum_tensor.data_ptr(), self.n_pixels, out_tensor.data_ptr(), self._stream())
+
+    def render(self):
+        """One frame; returns the (H, W, 3) image tensor (same storage every call)."""
+        self.sum.zero_()
+        if self.s_end > self.s_begin:
+            self._accumulate(self.cam, self.opt, self.s_begin, self.s_end, self.sum)
+        if self.world > 1:
+            self.dist.all_reduce(self.sum, group=self.group)
+        self._resolve(self.sum, self.image)
+        return self.image.view(self.cam.height, self.cam.width, 3)

@@ -45,6 +45,8 @@ def _load():
     lib.orc_random_cos.argtypes = [C.c_uint32, _f32p, _f32p, _f32p, C.c_int32, _f32p]
     lib.orc_primary_ray.argtypes = [C.POINTER(rt.Camera), C.POINTER(OrcOptions), C.c_uint32, C.c_uint32, _f32p, _u32p]
     lib.orc_uniforms.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
+    lib.orc_math_probe.argtypes = [C.c_int32, C.c_uint32, _f32p, _f32p]
+    lib.orc_math_probe.restype = C.c_int
     for n in ("orc_render_pixels", "orc_cast", "orc_visible", "orc_random_cos", "orc_primary_ray", "orc_uniforms"):
         getattr(lib, n).restype = C.c_int
     return lib
@@ -132,5 +134,15 @@ def primary_ray(cam, opt, pixel, sample):
 def uniforms(seed, pixel, sample, first_dim, n):
     out = np.empty(n, np.float32)
     rc = lib.orc_uniforms(seed, pixel, sample, first_dim, n, out.ctypes.data_as(_f32p))
+    assert rc == 0
+    return out
+
+
+def math_probe(kind, values):
+    """kind: 'log' | 'sin' | 'cos' | 'gamma' -> rt_math.h result per value."""
+    a = np.ascontiguousarray(values, np.float32)
+    out = np.empty_like(a)
+    rc = lib.orc_math_probe({"log": 0, "sin": 1, "cos": 2, "gamma": 3}[kind], a.size, a.ctypes.data_as(_f32p),
+                            out.ctypes.data_as(_f32p))
     assert rc == 0
     return out

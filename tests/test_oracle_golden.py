@@ -1,0 +1,160 @@
+"""Pins the CPU oracle (and the scene loader that feeds it) to what is known
+about the reference: recorded anchor pixels of its per-pixel routine, recorded
+loader statistics, recorded work-per-path counts and its shipped renders.
+Runs on CPU only.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle_binding as ob
+import raytracer_amd as rt
+from helpers import load, variant
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+with open(os.path.join(GOLDEN, "anchors.json")) as f:
+    ANCHORS = json.load(f)
+
+
+@pytest.mark.parametrize("use_libm", [True, False])
+@pytest.mark.parametrize("scene_name", ["simple", "mesh_scene"])
+@pytest.mark.parametrize("bbox", [True, False])
+def test_anchor_pixels(scene_name, use_libm, bbox):
+    """Deterministic mode (no AA, direct light): recorded output pixels of the reference routine."""
+    s = load(scene_name)
+    desc, cam = s.describe()
+    opt = ob.options(indirect=False, antialiasing=False, bounding_box=bbox, use_libm=use_libm)
+    entries = ANCHORS["scenes"][scene_name]["pixels"]
+    pixels = [e["pixel"][1] * cam.width + e["pixel"][0] for e in entries]
+    rgb, _, count, _ = ob.render_pixels(desc, cam, opt, pixels)
+    want = np.array([e["rgb"] for e in entries], np.float32)
+    # recorded with 6 decimals; the polynomial gamma differs from powf by < 1e-6 relative
+    np.testing.assert_allclose(rgb, want, rtol=2e-6, atol=1e-6)
+    assert np.all(count == 1)  # a diffuse first hit ends the sample loop after one ray
+
+
+def test_anchor_image_mean_simple():
+    s = load("simple")
+    desc, cam = s.describe()
+    opt = ob.options(indirect=False, antialiasing=False, bounding_box=True, use_libm=True)
+    img, _ = ob.render_image(desc, cam, opt)
+    mean = np.minimum(img, 255).reshape(-1, 3).astype(np.float64).mean(axis=0)
+    np.testing.assert_allclose(mean, ANCHORS["scenes"]["simple"]["mean"], atol=2e-4)
+
+
+def test_anchor_image_mean_cat():
+    s = load("mesh_scene")
+    desc, cam = s.describe()
+    opt = ob.options(indirect=False, antialiasing=False, bounding_box=True, use_libm=True)
+    img, _ = ob.render_image(desc, cam, opt)
+    mean = np.minimum(img, 255).reshape(-1, 3).astype(np.float64).mean(axis=0)
+    np.testing.assert_allclose(mean, ANCHORS["scenes"]["mesh_scene"]["mean"], atol=2e-4)
+
+
+def test_recorded_loader_statistics():
+    a = ANCHORS["scenes"]["mesh_scene"]
+    s = load("mesh_scene")
+    desc, _ = s.describe()
+    arr = rt.desc_arrays(desc)
+    assert desc.n_triangles == a["triangles"]
+    assert desc.n_vertices == a["vertices"]
+    assert desc.n_boxes == a["boxes"]
+    np.testing.assert_allclose(arr["box_min"][0], a["bbox_min"], atol=5e-5)
+    np.testing.assert_allclose(arr["box_max"][0], a["bbox_max"], atol=5e-5)
+
+
+def test_recorded_work_per_path():
+    """Casts, sphere tests and triangle tests per path of the headline configuration."""
+    w = ANCHORS["work_per_path"]["mesh_scene"]
+    s = load("mesh_scene", num_rays=2)
+    desc, cam = s.describe()
+    rng = np.random.default_rng(3)
+    pixels = rng.choice(cam.width * cam.height, 3000, replace=False)
+    _, _, _, c = ob.render_pixels(desc, cam, ob.options(), pixels)
+    paths = c["paths"]
+    assert c["casts"] / paths == pytest.approx(w["casts"], rel=1e-3)
+    assert c["sphere_tests"] / paths == pytest.approx(w["sphere_tests"], rel=1e-3)
+    assert c["box_tests"] / paths == pytest.approx(w["box_tests"], rel=1e-3)
+    # stochastic quantity: 6000 paths estimate the recorded 7 174 to a few percent
+    assert c["triangle_tests"] / paths == pytest.approx(w["triangle_tests"], rel=0.05)
+
+
+def test_recorded_work_per_path_default_scene():
+    w = ANCHORS["work_per_path"]["default"]
+    s = load("default", num_rays=2)
+    desc, cam = s.describe()
+    rng = np.random.default_rng(4)
+    pixels = rng.choice(cam.width * cam.height, 20000, replace=False)
+    _, _, _, c = ob.render_pixels(desc, cam, ob.options(bounding_box=False), pixels)
+    assert c["casts"] / c["paths"] == pytest.approx(w["casts"], rel=0.02)
+    assert c["sphere_tests"] / c["paths"] == pytest.approx(w["sphere_tests"], rel=0.02)
+
+
+def _reference_render(name, size):
+    img = Image.open(os.path.join(GOLDEN, "reference_renders", name)).convert("RGB")
+    w, h = img.size
+    a = np.asarray(img, np.float32)
+    f = w // size[0]
+    return a.reshape(size[1], f, size[0], f, 3).mean(axis=(1, 3))  # box filter down to the test size
+
+
+def _blur(a, r=2):
+    out = np.zeros_like(a)
+    n = 0
+    for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+            out += np.roll(np.roll(a, dy, 0), dx, 1)
+            n += 1
+    return out / n
+
+
+# (file, scene loader, (indirect, aa, bbox), per-channel mean tolerance, blurred RMSE tolerance), all in 8-bit units
+SHIPPED = [
+    ("cat_512x512_32rays_antialias-only.png", lambda: load("mesh_scene", 128, 128, 16), (False, True, True), 0.6, 3.0),
+    # drawn without anti-aliasing: its statistics match that mode only
+    ("cat_mirror_512x512_32rays.png", lambda: variant("mesh_scene", "mirror", 128, 128, 2), (False, False, True), 0.6, 4.0),
+    ("default_512x512_32rays_indirect.png", lambda: load("default", 128, 128, 48), (True, True, True), 1.5, 6.0),
+]
+
+
+@pytest.mark.parametrize("name,make,mode,mean_tol,rmse_tol", SHIPPED)
+def test_oracle_reproduces_shipped_renders(name, make, mode, mean_tol, rmse_tol):
+    """Statistical agreement with the reference's own images (drawn with an unknown seed),
+    compared at a quarter of their resolution to keep the CPU suite short."""
+    s = make()
+    desc, cam = s.describe()
+    opt = ob.options(*mode, seed=2, use_libm=True)
+    img, _ = ob.render_image(desc, cam, opt)
+    mine = np.floor(np.minimum(img, 255))  # the reference's float -> u8 conversion
+    ref = _reference_render(name, (cam.width, cam.height))
+    mean_diff = np.abs(mine.reshape(-1, 3).mean(0) - ref.reshape(-1, 3).mean(0))
+    rmse = float(np.sqrt(np.mean((_blur(mine) - _blur(ref)) ** 2)))
+    assert np.all(mean_diff < mean_tol), f"mean diff {mean_diff}"
+    assert rmse < rmse_tol, f"blurred rmse {rmse}"
+
+
+def test_libm_and_polynomial_oracles_agree():
+    """The two math back-ends differ by rounding only: same image up to rare decision flips."""
+    s = load("default", 64, 64, 4)
+    desc, cam = s.describe()
+    a, _ = ob.render_image(desc, cam, ob.options(seed=7, use_libm=True))
+    b, _ = ob.render_image(desc, cam, ob.options(seed=7, use_libm=False))
+    close = np.isclose(a, b, rtol=1e-4, atol=1e-3).all(axis=2)
+    assert close.mean() > 0.97
+    assert abs(a.mean() - b.mean()) < 0.3
+
+
+def test_sample_ranges_compose():
+    """Linear sums over [0,a) and [a,n) add up to the sum over [0,n) (sample-split invariance)."""
+    s = load("default", 32, 32, 6)
+    desc, cam = s.describe()
+    px = np.arange(cam.width * cam.height, dtype=np.uint32)
+    opt = ob.options(seed=11)
+    _, full, nf, _ = ob.render_pixels(desc, cam, opt, px, 0, 6)
+    _, a, na, _ = ob.render_pixels(desc, cam, opt, px, 0, 2)
+    _, b, nb, _ = ob.render_pixels(desc, cam, opt, px, 2, 6)
+    assert np.array_equal(na + nb, nf)
+    np.testing.assert_allclose(a + b, full, rtol=1e-5, atol=1e-3)
