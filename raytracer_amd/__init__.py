@@ -77,11 +77,36 @@ class RtError(RuntimeError):
         self.code = code
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch's ROCm wheels bundle their own libamdhip64.so with the same soname as the
+    system one; whichever is loaded first serves the whole process, and PyTorch finds no
+    GPU when it is not its own.  So when PyTorch is installed its copy is loaded first
+    (without importing torch), which makes the import order of the two packages
+    irrelevant.  RT_AMD_SYSTEM_HIP=1 keeps the system runtime."""
+    if os.environ.get("RT_AMD_SYSTEM_HIP") == "1":
+        return
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    candidate = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(candidate):
+        try:
+            C.CDLL(candidate, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
             "(or __graft_entry__.build()); there is no fallback path")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     sig = {
