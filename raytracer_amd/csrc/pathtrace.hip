@@ -99,7 +99,7 @@ struct Work {
     float4* pend;    // n_lights per path: contribution.xyz, light distance or PEND_*
     unsigned long long* hit; // paths + paths*n_lights slots: (t bits << 32) | triangle
     float4* q_o;     // queued ray origin.xyz, hit slot as uint bits
-    float4* q_d;     // queued ray direction.xyz
+    float4* q_d;     // queued ray direction.xyz, cut-off distance
     uint32_t* q_count; // kShards counters per k_mesh launch of a batch
     uint32_t shard_capacity; // queue entries reserved per shard
 };
@@ -199,7 +199,7 @@ __device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, V3 ray, V3 st
 // shards with a counter each and a wavefront always uses the shard of its own
 // index, which spreads the returning atomics over 64 addresses (one address
 // serialises at well under 200 atomics per microsecond).
-__device__ __forceinline__ void enqueue(const Work& w, uint32_t counter, bool want, V3 start, V3 ray, uint32_t slot) {
+__device__ __forceinline__ void enqueue(const Work& w, uint32_t counter, bool want, V3 start, V3 ray, uint32_t slot, float cutoff) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0) return;
     const uint32_t lane = __lane_id();
@@ -211,7 +211,7 @@ __device__ __forceinline__ void enqueue(const Work& w, uint32_t counter, bool wa
     if (want) {
         const size_t at = (size_t)shard * w.shard_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
         w.q_o[at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot));
-        w.q_d[at] = make_float4(ray.x, ray.y, ray.z, 0.f);
+        w.q_d[at] = make_float4(ray.x, ray.y, ray.z, cutoff);
     }
 }
 
@@ -240,32 +240,78 @@ __device__ __forceinline__ void barycentrics(const DeviceScene& sc, int tri, V3 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Exact tail of one ray-triangle test (reference src/raytrace.cu:161-174),
-// entered only by lanes the division-free test could not reject.
+// entered only by lanes the division-free test could not reject.  The running
+// minimum starts at the ray's cut-off distance (nearest sphere hit for a
+// bounce ray, light distance for a shadow ray): a triangle at or beyond it
+// cannot change the outcome, because spheres win ties (src/raytrace.cu:203-212)
+// and a shadow ray asks for t < distance (:240).  Among equal distances the
+// lower triangle index wins, as in the reference's in-order scan.
 __device__ __forceinline__ void exact_hit(float nb, float ng, float d, float ao_dot_n, uint32_t index, float& best, int& best_i) {
     const float beta = nb / d;
     const float gamma = -ng / d;
     const float alpha = 1.f - beta - gamma;
     if (alpha >= 0 && beta >= 0 && gamma >= 0) {
         const float t = ao_dot_n / d;
-        if (t > 0 && (best_i < 0 || t < best)) { best = t; best_i = (int)index; }
+        if (t > 0 && (t < best || (t == best && best_i >= 0 && (int)index < best_i))) { best = t; best_i = (int)index; }
+    }
+}
+
+// Twelve packed values of one triangle pair: A.xyz, e1.xyz, e2.xyz, N.xyz.
+struct PairData {
+    f2 v[12];
+};
+
+__device__ __forceinline__ PairData load_pair(const f2* __restrict__ tri2, uint32_t j) {
+    PairData p;
+    const f2* __restrict__ g = tri2 + 12 * (size_t)j;
+#pragma unroll
+    for (int k = 0; k < 12; k++) p.v[k] = g[k];
+    return p;
+}
+
+// One ray (lane) against the two triangles of a pair.  The numerators e2.q,
+// e1.q and the denominator u.N are computed with the reference's operation
+// order (src/raytrace.cu:155-162), two triangles at a time in packed fp32.
+// The division-free test uses an approximate reciprocal: a hit the reference
+// accepts has alpha, beta, gamma in [0, 1], where the approximations are off
+// by < 1e-6, so the 1e-5 margin never drops one; a NaN passes.
+__device__ __forceinline__ void test_pair(const PairData& p, uint32_t index0, uint32_t index1, float ox, float oy, float oz,
+                                          float ux, float uy, float uz, float& best, int& best_i) {
+    const f2 Ax = p.v[0], Ay = p.v[1], Az = p.v[2];
+    const f2 e1x = p.v[3], e1y = p.v[4], e1z = p.v[5];
+    const f2 e2x = p.v[6], e2y = p.v[7], e2z = p.v[8];
+    const f2 Nx = p.v[9], Ny = p.v[10], Nz = p.v[11];
+    const f2 aox = Ax - ox, aoy = Ay - oy, aoz = Az - oz;
+    const f2 qx = aoy * uz - aoz * uy;
+    const f2 qy = aoz * ux - aox * uz;
+    const f2 qz = aox * uy - aoy * ux;
+    const f2 d = (ux * Nx + uy * Ny) + uz * Nz;
+    const f2 nb = (e2x * qx + e2y * qy) + e2z * qz; // e2 . q
+    const f2 ng = (e1x * qx + e1y * qy) + e1z * qz; // e1 . q
+    f2 rcp;
+    rcp.x = __builtin_amdgcn_rcpf(d.x);
+    rcp.y = __builtin_amdgcn_rcpf(d.y);
+    const f2 b_ = nb * rcp;
+    const f2 g_ = -ng * rcp;
+    const f2 a_ = (1.f - b_) - g_;
+    const float lo0 = fminf(fminf(a_.x, b_.x), g_.x);
+    const float lo1 = fminf(fminf(a_.y, b_.y), g_.y);
+    if (!(lo0 < -1e-5f) || !(lo1 < -1e-5f)) {
+        const f2 aon = (aox * Nx + aoy * Ny) + aoz * Nz;
+        if (!(lo0 < -1e-5f)) exact_hit(nb.x, ng.x, d.x, aon.x, index0, best, best_i);
+        if (!(lo1 < -1e-5f)) exact_hit(nb.y, ng.y, d.y, aon.y, index1, best, best_i);
     }
 }
 
 // Every queued ray against every triangle (reference src/raytrace.cu:148-175).
 //
 // A lane owns a ray; the triangle index is wave-uniform, so triangle data
-// arrives by scalar loads and stays in SGPRs.  Two triangles are tested per
-// iteration with packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 work on
-// a register pair at the issue cost of one instruction): tri_pair holds every
-// quantity as (triangle 2j, triangle 2j+1), the ray components are broadcast.
-//
-// Per triangle a lane evaluates the reference's numerators e2.q, e1.q and
-// denominator u.N with the reference's operation order (bit-identical values)
-// and then a division-free test with an approximate reciprocal.  Only lanes
-// that may be inside a triangle take exact_hit with the reference's three IEEE
-// divisions.  A reference-accepted hit has alpha, beta, gamma in [0, 1], where
-// the approximate values are off by < 1e-6, so the 1e-5 margin never drops
-// one; a NaN passes the test.
+// arrives by scalar loads and stays in SGPRs (two register sets: the loads of
+// the next pair are in flight while the current pair is tested).  Two
+// triangles are tested per iteration with packed fp32 instructions
+// (v_pk_mul_f32 / v_pk_add_f32 work on a register pair at the issue cost of
+// one instruction): tri_pair holds every quantity as (triangle 2j, triangle
+// 2j+1), the ray components are broadcast.
 //
 // A job is 256 rays x one chunk of triangle pairs.  The nearest hit per ray is
 // merged across chunks with a 64-bit atomic minimum on (t bits, triangle),
@@ -310,37 +356,25 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, ui
         const float4 d4 = q_d[at];
         const float ox = o4.x, oy = o4.y, oz = o4.z;
         const float ux = d4.x, uy = d4.y, uz = d4.z;
-        float best = INFINITY;
+        float best = d4.w; // cut-off distance
         int best_i = -1;
         const uint32_t first = chunk * kChunkPairs;
         const uint32_t last = min(first + kChunkPairs, n_pairs);
-#pragma unroll 2
-        for (uint32_t j = first; j < last; j++) {
-            const f2* __restrict__ g = tri2 + 12 * (size_t)j;
-            const f2 Ax = g[0], Ay = g[1], Az = g[2];
-            const f2 e1x = g[3], e1y = g[4], e1z = g[5];
-            const f2 e2x = g[6], e2y = g[7], e2z = g[8];
-            const f2 Nx = g[9], Ny = g[10], Nz = g[11];
-            const f2 aox = Ax - ox, aoy = Ay - oy, aoz = Az - oz;
-            const f2 qx = aoy * uz - aoz * uy;
-            const f2 qy = aoz * ux - aox * uz;
-            const f2 qz = aox * uy - aoy * ux;
-            const f2 d = (ux * Nx + uy * Ny) + uz * Nz;
-            const f2 nb = (e2x * qx + e2y * qy) + e2z * qz; // e2 . q
-            const f2 ng = (e1x * qx + e1y * qy) + e1z * qz; // e1 . q
-            f2 rcp;
-            rcp.x = __builtin_amdgcn_rcpf(d.x);
-            rcp.y = __builtin_amdgcn_rcpf(d.y);
-            const f2 b_ = nb * rcp;
-            const f2 g_ = -ng * rcp;
-            const f2 a_ = (1.f - b_) - g_;
-            const float lo0 = fminf(fminf(a_.x, b_.x), g_.x);
-            const float lo1 = fminf(fminf(a_.y, b_.y), g_.y);
-            if (!(lo0 < -1e-5f) || !(lo1 < -1e-5f)) {
-                const f2 aon = (aox * Nx + aoy * Ny) + aoz * Nz;
-                if (!(lo0 < -1e-5f)) exact_hit(nb.x, ng.x, d.x, aon.x, 2 * j, best, best_i);
-                if (!(lo1 < -1e-5f)) exact_hit(nb.y, ng.y, d.y, aon.y, 2 * j + 1, best, best_i);
-            }
+        // Two pairs per trip, two SGPR sets.  Scalar loads return out of order,
+        // so the only wait available is "all of them": each set is therefore
+        // requested right after an explicit wait and just before the OTHER set
+        // is tested, which leaves exactly one request in flight during a test.
+        // Indices past the end are clamped and their tests skipped.
+        PairData cur = load_pair(tri2, first);
+        for (uint32_t j = first; j < last; j += 2) {
+            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): `cur` has landed
+            const PairData nxt = load_pair(tri2, min(j + 1, last - 1));
+            __builtin_amdgcn_sched_barrier(0); // keep the request ahead of the test it overlaps
+            test_pair(cur, 2 * j, 2 * j + 1, ox, oy, oz, ux, uy, uz, best, best_i);
+            __builtin_amdgcn_s_waitcnt(0xC07F); // `nxt` has landed
+            cur = load_pair(tri2, min(j + 2, last - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < last) test_pair(nxt, 2 * j + 2, 2 * j + 3, ox, oy, oz, ux, uy, uz, best, best_i);
         }
         if (active && best_i >= 0) {
             const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)best_i;
@@ -379,7 +413,7 @@ __device__ __forceinline__ void launch_ray(const DeviceScene& sc, const Work& w,
         w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
         w.hit[p] = kNoHit;
     }
-    enqueue(w, counter, walk, start, ray, p);
+    enqueue(w, counter, walk, start, ray, p, ts);
 }
 
 // Camera sample of every path of the batch (reference src/raytrace.cu:479-494).
@@ -563,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame 
                         } else {
                             L = L + c;
                         }
-                        enqueue(w, counter, walk, lifted, sray, (uint32_t)(f.n_paths + slot));
+                        enqueue(w, counter, walk, lifted, sray, (uint32_t)(f.n_paths + slot), dist);
                     }
                     if (deferred) flags |= F_PENDING;
                     if (!f.indirect) {
