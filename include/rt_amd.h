@@ -82,6 +82,12 @@ typedef struct rt_options {
     int32_t max_depth; /* 5 in the reference */
     uint32_t seed;
     int32_t profile;   /* non-zero: time the triangle kernel with events */
+    /* 0: every queued ray is tested against every triangle, the reference's
+     * scan (src/raytrace.cu:148-175).  Non-zero: triangles are grouped into
+     * clusters of 64 neighbours and a ray skips the clusters whose padded
+     * bounds it misses.  Same image unless the reference's rounding accepts a
+     * triangle for a ray that misses it by more than the padding. */
+    int32_t cluster_culling;
 } rt_options;
 
 /* Work executed by the most recent render / accumulate call. */

@@ -22,6 +22,7 @@
 // they do in the reference's float code.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -65,6 +66,9 @@ constexpr uint32_t kShards = 64;            // ray-queue shards = lanes of a wav
 constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none)
 constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
 constexpr uint32_t kMaxLights = 64;
+constexpr uint32_t kClusterPairs = 32;      // triangle pairs per culling cluster (64 triangles)
+constexpr uint32_t kMaxClusters = 1024;     // larger meshes get larger clusters
+constexpr size_t kClusterListBudget = size_t(8) << 30; // bytes for the per-cluster ray lists
 
 constexpr uint32_t F_ALIVE = 1u;   // the path still bounces
 constexpr uint32_t F_PENDING = 2u; // pend[] holds light contributions of the last hit
@@ -83,11 +87,16 @@ struct DeviceScene {
     const float4* tri_geom;   // 3 per triangle: A.xyz e1.x | e1.yz e2.xy | e2.z N.xyz
     const float2* tri_pair;   // 12 per PAIR of triangles (2j, 2j+1): A.x A.y A.z e1.xyz e2.xyz N.xyz,
                               // each as (value of 2j, value of 2j+1); k_mesh streams this one
+    const uint32_t* tri_orig; // caller's index of the triangle at each position of tri_pair
+                              // (triangles are stored in Morton order of their centroids)
+    const float4* cl_min;     // padded bounds of each cluster of cluster_pairs consecutive pairs
+    const float4* cl_max;
     const float4* tri_shade;  // 3 per triangle: n0.xyz material | n1.xyz - | n2.xyz -
     const float4* box_min;
     const float4* box_max;
     const float4* light;      // position.xyz, intensity
     uint32_t n_spheres, n_triangles, n_boxes, n_lights;
+    uint32_t n_clusters, cluster_pairs;
 };
 
 // Per-batch path state and queues.
@@ -102,6 +111,11 @@ struct Work {
     float4* q_d;     // queued ray direction.xyz, cut-off distance
     uint32_t* q_count; // kShards counters per k_mesh launch of a batch
     uint32_t shard_capacity; // queue entries reserved per shard
+    // cluster culling: per stage slot, the queue positions of the rays that touch each cluster
+    uint32_t* cl_count;      // n_clusters counters per slot
+    uint32_t* cl_first;      // n_clusters + 1 job prefix sums per slot
+    uint32_t* cl_list;       // n_clusters lists of list_capacity queue positions (reused by every slot)
+    uint32_t list_capacity;  // = rays binned per tile
 };
 
 struct V3 {
@@ -275,7 +289,7 @@ __device__ __forceinline__ PairData load_pair(const f2* __restrict__ tri2, uint3
 // The division-free test uses an approximate reciprocal: a hit the reference
 // accepts has alpha, beta, gamma in [0, 1], where the approximations are off
 // by < 1e-6, so the 1e-5 margin never drops one; a NaN passes.
-__device__ __forceinline__ void test_pair(const PairData& p, uint32_t index0, uint32_t index1, float ox, float oy, float oz,
+__device__ __forceinline__ void test_pair(const PairData& p, const uint32_t* __restrict__ orig, float ox, float oy, float oz,
                                           float ux, float uy, float uz, float& best, int& best_i) {
     const f2 Ax = p.v[0], Ay = p.v[1], Az = p.v[2];
     const f2 e1x = p.v[3], e1y = p.v[4], e1z = p.v[5];
@@ -298,84 +312,225 @@ __device__ __forceinline__ void test_pair(const PairData& p, uint32_t index0, ui
     const float lo1 = fminf(fminf(a_.y, b_.y), g_.y);
     if (!(lo0 < -1e-5f) || !(lo1 < -1e-5f)) {
         const f2 aon = (aox * Nx + aoy * Ny) + aoz * Nz;
-        if (!(lo0 < -1e-5f)) exact_hit(nb.x, ng.x, d.x, aon.x, index0, best, best_i);
-        if (!(lo1 < -1e-5f)) exact_hit(nb.y, ng.y, d.y, aon.y, index1, best, best_i);
+        if (!(lo0 < -1e-5f)) exact_hit(nb.x, ng.x, d.x, aon.x, orig[0], best, best_i);
+        if (!(lo1 < -1e-5f)) exact_hit(nb.y, ng.y, d.y, aon.y, orig[1], best, best_i);
     }
 }
 
-// Every queued ray against every triangle (reference src/raytrace.cu:148-175).
-//
-// A lane owns a ray; the triangle index is wave-uniform, so triangle data
-// arrives by scalar loads and stays in SGPRs (two register sets: the loads of
-// the next pair are in flight while the current pair is tested).  Two
-// triangles are tested per iteration with packed fp32 instructions
-// (v_pk_mul_f32 / v_pk_add_f32 work on a register pair at the issue cost of
-// one instruction): tri_pair holds every quantity as (triangle 2j, triangle
-// 2j+1), the ray components are broadcast.
-//
-// A job is 256 rays x one chunk of triangle pairs.  The nearest hit per ray is
-// merged across chunks with a 64-bit atomic minimum on (t bits, triangle),
-// which orders by distance first and triangle index second: the reference's
-// "first triangle wins ties".  Jobs are dealt so that the chunks of one ray
-// block run on workgroups with equal blockIdx % 8, which share an L2.
-__global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, uint32_t n_tri,
-                                                 const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                 const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
-                                                 unsigned long long* __restrict__ hit) {
-    // lane l of every wavefront holds shard l's ray count and the number of
-    // 256-ray blocks in the shards before it
+// Lane l of every wavefront holds shard l's ray count and the number of
+// 256-ray blocks in the shards before it.
+struct ShardMap {
+    uint32_t my_count, before, n_ray_blocks;
+};
+
+__device__ __forceinline__ ShardMap load_shard_map(const uint32_t* __restrict__ q_count) {
+    ShardMap m;
     const uint32_t lane = __lane_id();
-    const uint32_t my_count = q_count[lane];
-    const uint32_t my_blocks = (my_count + kBlock - 1) / kBlock;
+    m.my_count = q_count[lane];
+    const uint32_t my_blocks = (m.my_count + kBlock - 1) / kBlock;
     uint32_t incl = my_blocks;
 #pragma unroll
     for (int step = 1; step < 64; step <<= 1) {
         const uint32_t up = __shfl_up(incl, step);
         if ((int)lane >= step) incl += up;
     }
-    const uint32_t before = incl - my_blocks;
-    const uint32_t n_ray_blocks = __shfl(incl, 63);
-    if (n_ray_blocks == 0) return;
+    m.before = incl - my_blocks;
+    m.n_ray_blocks = __shfl(incl, 63);
+    return m;
+}
 
+// Queue position of this lane's ray in ray block `ray_block`; lanes past the
+// end of the shard get the shard's last ray and active = false.
+__device__ __forceinline__ uint32_t ray_position(const ShardMap& m, uint32_t ray_block, uint32_t shard_capacity, bool& active) {
+    const uint32_t shard = (uint32_t)__popcll(__ballot(m.before <= ray_block)) - 1u; // `before` is non-decreasing
+    const uint32_t shard_first = __shfl(m.before, (int)shard);
+    const uint32_t count = __shfl(m.my_count, (int)shard);
+    const uint32_t r = (ray_block - shard_first) * kBlock + threadIdx.x;
+    active = r < count;
+    return shard * shard_capacity + (active ? r : count - 1);
+}
+
+// One ray per lane against triangle pairs [first, last): two pairs per trip,
+// two SGPR sets.  Scalar loads return out of order, so the only wait available
+// is "all of them": each set is therefore requested right after an explicit
+// wait and just before the OTHER set is tested, which leaves exactly one
+// request in flight during a test.  Indices past the end are clamped and
+// their tests skipped.
+__device__ __forceinline__ void scan_pairs(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t first,
+                                           uint32_t last, float ox, float oy, float oz, float ux, float uy, float uz,
+                                           float& best, int& best_i) {
+    PairData cur = load_pair(tri2, first);
+    for (uint32_t j = first; j < last; j += 2) {
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): `cur` has landed
+        const PairData nxt = load_pair(tri2, min(j + 1, last - 1));
+        __builtin_amdgcn_sched_barrier(0); // keep the request ahead of the test it overlaps
+        test_pair(cur, tri_orig + 2 * (size_t)j, ox, oy, oz, ux, uy, uz, best, best_i);
+        __builtin_amdgcn_s_waitcnt(0xC07F); // `nxt` has landed
+        cur = load_pair(tri2, min(j + 2, last - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < last) test_pair(nxt, tri_orig + 2 * (size_t)j + 2, ox, oy, oz, ux, uy, uz, best, best_i);
+    }
+}
+
+// Every queued ray against every triangle (reference src/raytrace.cu:148-175).
+//
+// A lane owns a ray; the triangle index is wave-uniform, so triangle data
+// arrives by scalar loads and stays in SGPRs.  Two triangles are tested per
+// iteration with packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 work on
+// a register pair at the issue cost of one instruction): tri_pair holds every
+// quantity as (triangle 2j, triangle 2j+1), the ray components are broadcast.
+//
+// A job is 256 rays x one chunk of triangle pairs.  The nearest hit per ray is
+// merged across chunks with a 64-bit atomic minimum on (t bits, triangle),
+// which orders by distance first and triangle index second: the reference's
+// "first triangle wins ties".  Jobs are dealt so that the chunks of one ray
+// block run on workgroups with equal blockIdx % 8, which share an L2.
+__global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
+                                                 const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                 const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
+                                                 unsigned long long* __restrict__ hit) {
+    const ShardMap map = load_shard_map(q_count);
+    if (map.n_ray_blocks == 0) return;
     const uint32_t n_pairs = (n_tri + 1) / 2;
     const uint32_t n_chunks = (n_pairs + kChunkPairs - 1) / kChunkPairs;
     const uint32_t xcd = blockIdx.x % 8;
-    const uint32_t per_xcd = ((n_ray_blocks + 7) / 8) * n_chunks;
+    const uint32_t per_xcd = ((map.n_ray_blocks + 7) / 8) * n_chunks;
     for (uint32_t q = blockIdx.x / 8; q < per_xcd; q += gridDim.x / 8) {
         const uint32_t ray_block = (q / n_chunks) * 8 + xcd;
-        if (ray_block >= n_ray_blocks) continue;
+        if (ray_block >= map.n_ray_blocks) continue;
         const uint32_t chunk = q % n_chunks;
-        // shard that holds this ray block: the last one whose prefix is <= it
-        const uint32_t shard = (uint32_t)__popcll(__ballot(before <= ray_block)) - 1u; // `before` is non-decreasing
-        const uint32_t shard_first = __shfl(before, (int)shard);
-        const uint32_t count = __shfl(my_count, (int)shard);
-        const uint32_t r = (ray_block - shard_first) * kBlock + threadIdx.x;
-        const bool active = r < count;
-        const size_t at = (size_t)shard * shard_capacity + (active ? r : count - 1); // idle lanes shadow a real ray
+        bool active;
+        const uint32_t at = ray_position(map, ray_block, shard_capacity, active);
         const float4 o4 = q_o[at];
         const float4 d4 = q_d[at];
-        const float ox = o4.x, oy = o4.y, oz = o4.z;
-        const float ux = d4.x, uy = d4.y, uz = d4.z;
         float best = d4.w; // cut-off distance
         int best_i = -1;
         const uint32_t first = chunk * kChunkPairs;
-        const uint32_t last = min(first + kChunkPairs, n_pairs);
-        // Two pairs per trip, two SGPR sets.  Scalar loads return out of order,
-        // so the only wait available is "all of them": each set is therefore
-        // requested right after an explicit wait and just before the OTHER set
-        // is tested, which leaves exactly one request in flight during a test.
-        // Indices past the end are clamped and their tests skipped.
-        PairData cur = load_pair(tri2, first);
-        for (uint32_t j = first; j < last; j += 2) {
-            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): `cur` has landed
-            const PairData nxt = load_pair(tri2, min(j + 1, last - 1));
-            __builtin_amdgcn_sched_barrier(0); // keep the request ahead of the test it overlaps
-            test_pair(cur, 2 * j, 2 * j + 1, ox, oy, oz, ux, uy, uz, best, best_i);
-            __builtin_amdgcn_s_waitcnt(0xC07F); // `nxt` has landed
-            cur = load_pair(tri2, min(j + 2, last - 1));
-            __builtin_amdgcn_sched_barrier(0);
-            if (j + 1 < last) test_pair(nxt, 2 * j + 2, 2 * j + 3, ox, oy, oz, ux, uy, uz, best, best_i);
+        scan_pairs(tri2, tri_orig, first, min(first + kChunkPairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best, best_i);
+        if (active && best_i >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)best_i;
+            atomicMin(&hit[__float_as_uint(o4.w)], key);
         }
+    }
+}
+
+// ---- cluster culling ------------------------------------------------------
+//
+// The reference tests every triangle once any object box is hit
+// (src/raytrace.cu:136-148).  A triangle can only be hit by a ray that passes
+// through the (padded) bounds of the cluster of 64 spatially adjacent
+// triangles it belongs to, before the ray's cut-off distance.  k_bin lists, per
+// cluster, the queued rays that do; k_plan turns the list lengths into job
+// offsets; k_mesh_clusters runs the same pair scan as k_mesh over each
+// cluster's list.  The image is the exhaustive scan's, bit for bit, unless the
+// reference's own rounding makes it accept a triangle for a ray that misses
+// the triangle by more than the padding (a grazing ray whose barycentrics are
+// rounding noise); rt_options.cluster_culling = 0 selects the exhaustive scan.
+
+// Counters of different clusters sit on different 128-byte lines: atomics to
+// one line serialise, whatever word of it they touch.
+constexpr uint32_t kCountStride = 32;
+
+// Slab test of a ray against padded cluster bounds, up to the ray's cut-off
+// distance.  fminf/fmaxf drop the NaN of 0 * inf (origin on a slab plane,
+// direction parallel to it), which errs on the side of "touches".
+__device__ __forceinline__ bool touches(float4 lo, float4 hi, float4 o4, float ix, float iy, float iz, float cutoff) {
+    const float ax = (lo.x - o4.x) * ix, bx = (hi.x - o4.x) * ix;
+    const float ay = (lo.y - o4.y) * iy, by = (hi.y - o4.y) * iy;
+    const float az = (lo.z - o4.z) * iz, bz = (hi.z - o4.z) * iz;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return t_out >= fmaxf(t_in, 0.f) && t_in <= cutoff;
+}
+
+// Two passes over the clusters per block of 256 rays: count the touching rays
+// per (cluster, wavefront) in LDS, reserve list space with ONE atomic per
+// cluster and workgroup, then write the queue positions.
+__global__ __launch_bounds__(kBlock) void k_bin(DeviceScene sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
+                                                uint32_t first_block, uint32_t blocks_in_tile,
+                                                uint32_t* __restrict__ cl_count, uint32_t* __restrict__ cl_list, uint32_t list_capacity) {
+    __shared__ uint32_t slot[kMaxClusters][kWavesPerBlock]; // counts, then list offsets
+    const ShardMap map = load_shard_map(q_count);
+    const uint32_t end = min(first_block + blocks_in_tile, map.n_ray_blocks);
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t ray_block = first_block + blockIdx.x; ray_block < end; ray_block += gridDim.x) {
+        bool active;
+        const uint32_t at = ray_position(map, ray_block, shard_capacity, active);
+        const float4 o4 = q_o[at];
+        const float4 d4 = q_d[at];
+        const float ix = 1.f / d4.x, iy = 1.f / d4.y, iz = 1.f / d4.z; // +-inf for an axis-parallel ray
+        for (uint32_t c = 0; c < sc.n_clusters; c++) {
+            const bool touch = active && touches(sc.cl_min[c], sc.cl_max[c], o4, ix, iy, iz, d4.w);
+            const unsigned long long mask = __ballot(touch);
+            if (lane == 0) slot[c][wave] = (uint32_t)__popcll(mask);
+        }
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < sc.n_clusters; c += kBlock) {
+            uint32_t n[kWavesPerBlock], total = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kWavesPerBlock; k++) { n[k] = slot[c][k]; total += n[k]; }
+            uint32_t base = total ? atomicAdd(&cl_count[c * kCountStride], total) : 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kWavesPerBlock; k++) { slot[c][k] = base; base += n[k]; }
+        }
+        __syncthreads();
+        for (uint32_t c = 0; c < sc.n_clusters; c++) {
+            const bool touch = active && touches(sc.cl_min[c], sc.cl_max[c], o4, ix, iy, iz, d4.w);
+            const unsigned long long mask = __ballot(touch);
+            if (touch) cl_list[(size_t)c * list_capacity + slot[c][wave] + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL))] = at;
+        }
+        __syncthreads();
+    }
+}
+
+// cl_first[c] = number of 256-ray jobs of the clusters before c; cl_first[n] = total.
+__global__ __launch_bounds__(1024) void k_plan(const uint32_t* __restrict__ cl_count, uint32_t n_clusters, uint32_t* __restrict__ cl_first) {
+    __shared__ uint32_t scan[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t jobs = t < n_clusters ? (cl_count[t * kCountStride] + kBlock - 1) / kBlock : 0;
+    scan[t] = jobs;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = t >= off ? scan[t - off] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    if (t < n_clusters) cl_first[t] = scan[t] - jobs;
+    if (t == 1023) cl_first[n_clusters] = scan[1023];
+}
+
+__global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
+                                                          uint32_t n_clusters, uint32_t cluster_pairs,
+                                                          const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                          const uint32_t* __restrict__ cl_count, const uint32_t* __restrict__ cl_first,
+                                                          const uint32_t* __restrict__ cl_list, uint32_t list_capacity,
+                                                          unsigned long long* __restrict__ hit) {
+    __shared__ uint32_t first_job[kMaxClusters + 1];
+    for (uint32_t i = threadIdx.x; i <= n_clusters; i += kBlock) first_job[i] = cl_first[i];
+    __syncthreads();
+    const uint32_t n_jobs = first_job[n_clusters];
+    const uint32_t n_pairs = (n_tri + 1) / 2;
+    for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+        // the last cluster whose first job is <= job (empty clusters share their successor's value)
+        uint32_t lo = 0, hi = n_clusters - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) / 2;
+            if (first_job[mid] <= job) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t c = lo;
+        const uint32_t count = cl_count[c * kCountStride];
+        const uint32_t e = (job - first_job[c]) * kBlock + threadIdx.x;
+        const bool active = e < count;
+        const uint32_t at = cl_list[(size_t)c * list_capacity + (active ? e : count - 1)];
+        const float4 o4 = q_o[at];
+        const float4 d4 = q_d[at];
+        float best = d4.w;
+        int best_i = -1;
+        const uint32_t first = c * cluster_pairs;
+        scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best, best_i);
         if (active && best_i >= 0) {
             const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)best_i;
             atomicMin(&hit[__float_as_uint(o4.w)], key);
@@ -757,6 +912,8 @@ struct rt_scene {
     std::vector<void*> work_allocations;
     uint32_t work_paths = 0;
     uint32_t n_counters = 0;
+    uint32_t tiles = 1;                  // cluster-list tiles per k_mesh stage
+    std::vector<uint32_t> cluster_tris;  // triangles per culling cluster
     // profiling events
     std::vector<hipEvent_t> events;
 };
@@ -848,17 +1005,33 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t n_waves = (((size_t)n_paths + kBlock - 1) / kBlock) * kWavesPerBlock;
     const size_t shard_capacity = ((n_waves + kShards - 1) / kShards) * 64 * (1 + nl);
     const size_t queue_entries = shard_capacity * kShards;
-    if (shard_capacity > 0xffffffffu) { rt_set_error("batch too large for the ray queue"); return RT_ERR_INVALID; }
+    if (queue_entries > 0xffffffffu) { rt_set_error("batch too large for the ray queue"); return RT_ERR_INVALID; }
+    // cluster lists: one tile of rays at a time if the whole queue would not fit the budget
+    const size_t nc = s->d.n_clusters;
+    size_t list_capacity = 0, tiles = 1;
+    if (nc > 1) {
+        // a tile is a range of 256-ray blocks; every shard may end in a partial block
+        const size_t max_blocks = ((shard_capacity + kBlock - 1) / kBlock) * kShards;
+        list_capacity = kClusterListBudget / (4 * nc) / kBlock * kBlock;
+        if (list_capacity > max_blocks * kBlock) list_capacity = max_blocks * kBlock;
+        if (list_capacity < kBlock) list_capacity = kBlock;
+        tiles = (max_blocks + list_capacity / kBlock - 1) / (list_capacity / kBlock);
+    }
+    const size_t slots_cl = (size_t)n_counters * tiles;
     int rc;
     if ((rc = work_alloc(s, &s->w.ray_o, n_paths)) || (rc = work_alloc(s, &s->w.ray_d, n_paths)) ||
         (rc = work_alloc(s, &s->w.thr, n_paths)) || (rc = work_alloc(s, &s->w.rad, n_paths)) ||
         (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
         (rc = work_alloc(s, &s->w.q_o, queue_entries)) || (rc = work_alloc(s, &s->w.q_d, queue_entries)) ||
-        (rc = work_alloc(s, &s->w.q_count, (size_t)n_counters * kShards))) {
+        (rc = work_alloc(s, &s->w.q_count, (size_t)n_counters * kShards)) ||
+        (rc = work_alloc(s, &s->w.cl_count, slots_cl * nc * kCountStride)) || (rc = work_alloc(s, &s->w.cl_first, slots_cl * (nc + 1))) ||
+        (rc = work_alloc(s, &s->w.cl_list, nc * list_capacity))) {
         free_work(s);
         return rc;
     }
     s->w.shard_capacity = (uint32_t)shard_capacity;
+    s->w.list_capacity = (uint32_t)list_capacity;
+    s->tiles = (uint32_t)tiles;
     s->work_paths = n_paths;
     s->n_counters = n_counters;
     return RT_OK;
@@ -881,7 +1054,9 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     return f;
 }
 
-int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile) {
+// One k_mesh stage: the queued rays of `counter` against the mesh, either by
+// the exhaustive scan or through the cluster lists.
+int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile, bool cull) {
     if (s->d.n_triangles == 0) return RT_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile) {
@@ -891,9 +1066,27 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile)
         s->events.push_back(e1);
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    hipLaunchKernelGGL(k_mesh, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.tri_pair),
-                       s->d.n_triangles, (const float4*)s->w.q_o, (const float4*)s->w.q_d,
-                       (const uint32_t*)(s->w.q_count + (size_t)counter * kShards), s->w.shard_capacity, s->w.hit);
+    const f2* tri2 = reinterpret_cast<const f2*>(s->d.tri_pair);
+    const uint32_t* q_count = s->w.q_count + (size_t)counter * kShards;
+    if (cull && s->d.n_clusters > 1) {
+        const uint32_t nc = s->d.n_clusters;
+        const uint32_t blocks_per_tile = s->w.list_capacity / kBlock;
+        for (uint32_t tile = 0; tile < s->tiles; tile++) {
+            const size_t slot = (size_t)counter * s->tiles + tile;
+            uint32_t* cl_count = s->w.cl_count + slot * nc * kCountStride;
+            uint32_t* cl_first = s->w.cl_first + slot * (nc + 1);
+            hipLaunchKernelGGL(k_bin, dim3(kMeshGrid), dim3(kBlock), 0, stream, s->d, (const float4*)s->w.q_o, (const float4*)s->w.q_d,
+                               q_count, s->w.shard_capacity, tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list,
+                               s->w.list_capacity);
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cl_count, nc, cl_first);
+            hipLaunchKernelGGL(k_mesh_clusters, dim3(kMeshGrid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
+                               s->d.cluster_pairs, (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)cl_count,
+                               (const uint32_t*)cl_first, (const uint32_t*)s->w.cl_list, s->w.list_capacity, s->w.hit);
+        }
+    } else {
+        hipLaunchKernelGGL(k_mesh, dim3(kMeshGrid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles,
+                           (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity, s->w.hit);
+    }
     HIP_TRY(hipGetLastError());
     if (profile) HIP_TRY(hipEventRecord(e1, stream));
     return RT_OK;
@@ -932,6 +1125,7 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     // plain float subtractions and products, so the stored values are the
     // ones the reference recomputes for every ray.
     std::vector<float4> geom(3 * (size_t)d->n_triangles), shade(3 * (size_t)d->n_triangles);
+    float mesh_lo[3] = {INFINITY, INFINITY, INFINITY}, mesh_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = 0; i < d->n_triangles; i++) {
         const float* A = d->vertices + 3 * d->tri_v[3 * i + 0];
         const float* B = d->vertices + 3 * d->tri_v[3 * i + 1];
@@ -947,20 +1141,84 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
         for (int k = 0; k < 3; k++) {
             const float* n = d->normals + 3 * d->tri_n[3 * i + k];
             shade[3 * i + k] = make_float4(n[0], n[1], n[2], k == 0 ? mat_bits : 0.f);
+            const float* v = d->vertices + 3 * d->tri_v[3 * i + k];
+            for (int a = 0; a < 3; a++) {
+                if (v[a] < mesh_lo[a]) mesh_lo[a] = v[a];
+                if (v[a] > mesh_hi[a]) mesh_hi[a] = v[a];
+            }
         }
     }
-    // the same twelve numbers per triangle, interleaved two triangles at a time
+    // Scan order of the triangle kernel: Morton order of the centroids, so
+    // that consecutive triangles are neighbours in space and a cluster of them
+    // has tight bounds.  Hits carry the caller's index (tri_orig) and ties are
+    // resolved on it, so the order does not change any result.
+    std::vector<uint32_t> order(d->n_triangles);
+    {
+        std::vector<uint64_t> keyed(d->n_triangles);
+        auto spread = [](uint32_t x) {
+            x &= 0x3ff;
+            x = (x | (x << 16)) & 0x030000ff;
+            x = (x | (x << 8)) & 0x0300f00f;
+            x = (x | (x << 4)) & 0x030c30c3;
+            x = (x | (x << 2)) & 0x09249249;
+            return x;
+        };
+        for (uint32_t i = 0; i < d->n_triangles; i++) {
+            uint32_t code = 0;
+            for (int a = 0; a < 3; a++) {
+                double c = 0;
+                for (int k = 0; k < 3; k++) c += d->vertices[3 * d->tri_v[3 * i + k] + a];
+                const double extent = (double)mesh_hi[a] - mesh_lo[a];
+                double u = extent > 0 ? (c / 3 - mesh_lo[a]) / extent : 0.0;
+                if (!(u >= 0)) u = 0;  // also catches NaN coordinates
+                if (u > 1) u = 1;
+                code |= spread((uint32_t)(u * 1023.0)) << a;
+            }
+            keyed[i] = ((uint64_t)code << 32) | i;
+        }
+        std::sort(keyed.begin(), keyed.end());
+        for (uint32_t i = 0; i < d->n_triangles; i++) order[i] = (uint32_t)keyed[i];
+    }
+    // The same twelve numbers per triangle, interleaved two triangles at a time
     // for the packed-fp32 inner loop; an odd count is padded with an all-zero
-    // triangle, whose zero denominator can never produce a hit
+    // triangle, whose zero denominator can never produce a hit.
     const size_t n_pairs = ((size_t)d->n_triangles + 1) / 2;
     std::vector<float2> pair(12 * n_pairs, make_float2(0.f, 0.f));
-    for (uint32_t i = 0; i < d->n_triangles; i++) {
+    std::vector<uint32_t> orig(2 * n_pairs, 0xffffffffu);
+    for (uint32_t pos = 0; pos < d->n_triangles; pos++) {
+        const uint32_t i = order[pos];
+        orig[pos] = i;
         const float4 g0 = geom[3 * i + 0], g1 = geom[3 * i + 1], g2 = geom[3 * i + 2];
         const float v[12] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w};
         for (int k = 0; k < 12; k++) {
-            float2& dst = pair[12 * (size_t)(i / 2) + k];
-            if (i & 1) dst.y = v[k]; else dst.x = v[k];
+            float2& dst = pair[12 * (size_t)(pos / 2) + k];
+            if (pos & 1) dst.y = v[k]; else dst.x = v[k];
         }
+    }
+    // Clusters of consecutive pairs and their bounds, padded by 0.05 plus a
+    // thousandth of the cluster's diagonal.
+    uint32_t cluster_pairs = kClusterPairs;
+    while ((n_pairs + cluster_pairs - 1) / cluster_pairs > kMaxClusters) cluster_pairs *= 2;
+    const uint32_t n_clusters = (uint32_t)((n_pairs + cluster_pairs - 1) / cluster_pairs);
+    std::vector<float4> cl_min(n_clusters), cl_max(n_clusters);
+    std::vector<uint32_t> cluster_tris(n_clusters, 0);
+    for (uint32_t c = 0; c < n_clusters; c++) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        const size_t begin = (size_t)c * cluster_pairs * 2;
+        const size_t end = std::min<size_t>(begin + (size_t)cluster_pairs * 2, d->n_triangles);
+        cluster_tris[c] = (uint32_t)(end - begin);
+        for (size_t pos = begin; pos < end; pos++)
+            for (int k = 0; k < 3; k++) {
+                const float* v = d->vertices + 3 * d->tri_v[3 * order[pos] + k];
+                for (int a = 0; a < 3; a++) {
+                    if (v[a] < lo[a]) lo[a] = v[a];
+                    if (v[a] > hi[a]) hi[a] = v[a];
+                }
+            }
+        const float diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+        const float pad = 0.05f + 1e-3f * diag;
+        cl_min[c] = make_float4(lo[0] - pad, lo[1] - pad, lo[2] - pad, 0.f);
+        cl_max[c] = make_float4(hi[0] + pad, hi[1] + pad, hi[2] + pad, 0.f);
     }
     std::vector<float4> box_min(d->n_boxes), box_max(d->n_boxes), light(d->n_lights);
     for (uint32_t i = 0; i < d->n_boxes; i++) {
@@ -975,9 +1233,13 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     s->d.n_triangles = d->n_triangles;
     s->d.n_boxes = d->n_boxes;
     s->d.n_lights = d->n_lights;
+    s->d.n_clusters = n_clusters;
+    s->d.cluster_pairs = cluster_pairs;
+    s->cluster_tris = cluster_tris;
     if ((rc = upload(s, sphere, &s->d.sphere)) || (rc = upload(s, sphere_mat, &s->d.sphere_mat)) ||
         (rc = upload(s, mat_color, &s->d.mat_color)) || (rc = upload(s, mat_ior, &s->d.mat_ior)) ||
-        (rc = upload(s, geom, &s->d.tri_geom)) || (rc = upload(s, pair, &s->d.tri_pair)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
+        (rc = upload(s, geom, &s->d.tri_geom)) || (rc = upload(s, pair, &s->d.tri_pair)) || (rc = upload(s, orig, &s->d.tri_orig)) ||
+        (rc = upload(s, cl_min, &s->d.cl_min)) || (rc = upload(s, cl_max, &s->d.cl_max)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
         (rc = upload(s, box_min, &s->d.box_min)) || (rc = upload(s, box_max, &s->d.box_max)) ||
         (rc = upload(s, light, &s->d.light))) {
         rt_scene_free(s);
@@ -1015,6 +1277,10 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
     if ((rc = ensure_work(s, per_batch * n_pixels, n_counters)) != RT_OK) return rc;
 
     const bool profile = stats && opt->profile;
+    const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
+    const size_t cl_words = cull ? (size_t)n_counters * s->tiles * s->d.n_clusters * kCountStride : 0;
+    std::vector<uint32_t> cl_counts(cl_words);
+    uint64_t tests = 0;
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     s->events.clear();
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1033,14 +1299,15 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         f.sample_begin = sample_begin + first;
         const dim3 grid((f.n_paths + kBlock - 1) / kBlock), block(kBlock);
         HIP_TRY(hipMemsetAsync(s->w.q_count, 0, counts.size() * sizeof(uint32_t), stream));
+        if (cull) HIP_TRY(hipMemsetAsync(s->w.cl_count, 0, cl_words * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_generate, grid, block, 0, stream, s->d, s->w, f);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
-            if ((rc = launch_mesh(s, (uint32_t)depth, stream, profile)) != RT_OK) return rc;
+            if ((rc = launch_mesh(s, (uint32_t)depth, stream, profile, cull)) != RT_OK) return rc;
             hipLaunchKernelGGL(k_shade, grid, block, 0, stream, s->d, s->w, f, depth);
             HIP_TRY(hipGetLastError());
         }
-        if ((rc = launch_mesh(s, (uint32_t)opt->max_depth, stream, profile)) != RT_OK) return rc;
+        if ((rc = launch_mesh(s, (uint32_t)opt->max_depth, stream, profile, cull)) != RT_OK) return rc;
         hipLaunchKernelGGL(k_accumulate, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, s->d, s->w, f,
                            reinterpret_cast<float4*>(d_sum));
         HIP_TRY(hipGetLastError());
@@ -1048,8 +1315,16 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         paths += f.n_paths;
         if (stats) { // the counters are reused by the next batch: read them now
             HIP_TRY(hipMemcpyAsync(counts.data(), s->w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), s->w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            for (uint32_t c : counts) mesh_rays += c;
+            uint64_t batch_rays = 0;
+            for (uint32_t c : counts) batch_rays += c;
+            mesh_rays += batch_rays;
+            if (cull) {
+                for (size_t i = 0; i < cl_words; i += kCountStride) tests += (uint64_t)cl_counts[i] * s->cluster_tris[(i / kCountStride) % s->d.n_clusters];
+            } else {
+                tests += batch_rays * s->d.n_triangles;
+            }
         }
     }
     if (stats) {
@@ -1069,7 +1344,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         stats->batches = batches;
         stats->paths = paths;
         stats->mesh_rays = mesh_rays;
-        stats->triangle_tests = mesh_rays * s->d.n_triangles;
+        stats->triangle_tests = tests;
         stats->sphere_casts = sphere_casts;
     }
     return RT_OK;
@@ -1143,7 +1418,9 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
         if (hipMemcpy(d_a, a, 3 * (size_t)n * 4, hipMemcpyHostToDevice) || hipMemcpy(d_b, b, 3 * (size_t)n * 4, hipMemcpyHostToDevice) ||
             hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(s->w.q_count, 0, 2 * kShards * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, s->w, f, (const float*)d_a, (const float*)d_b, as_segments);
-        if (launch_mesh(s, 0, nullptr, false) != RT_OK) { rc = RT_ERR_DEVICE; break; }
+        const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
+        if (cull && hipMemset(s->w.cl_count, 0, (size_t)2 * s->tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        if (launch_mesh(s, 0, nullptr, false, cull) != RT_OK) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, s->w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }
         if (as_segments) {

@@ -463,6 +463,7 @@ rt_options options_from(const RenderSettings& s, size_t seed) {
     o.bounding_box = s.bounding_box;
     o.max_depth = s.max_ray_depth;
     o.seed = static_cast<uint32_t>(seed);
+    o.cluster_culling = s.cluster_culling;
     return o;
 }
 
@@ -743,6 +744,7 @@ int rt_host_scene_set_options(rt_host_scene* s, const rt_options* opt) {
     s->scene.settings.antialiasing = opt->antialiasing != 0;
     s->scene.settings.bounding_box = opt->bounding_box != 0;
     s->scene.settings.max_ray_depth = opt->max_depth;
+    s->scene.settings.cluster_culling = opt->cluster_culling != 0;
     return RT_OK;
 }
 

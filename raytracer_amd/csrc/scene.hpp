@@ -88,6 +88,9 @@ struct RenderSettings {
     bool antialiasing = true;
     bool bounding_box = true;
     int max_ray_depth = 5;
+    // not in the reference: skip clusters of triangles whose bounds a ray misses
+    // (false = the reference's exhaustive triangle scan)
+    bool cluster_culling = true;
 };
 
 class Scene {

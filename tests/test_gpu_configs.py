@@ -65,7 +65,8 @@ def test_c2_default_indirect_aa_full_size():
 
 
 def test_c3_cat_indirect_aa_bbox_full_size():
-    img, st = check_subset(load("mesh_scene"), rt.make_options(seed=1), 1500)
+    check_subset(load("mesh_scene"), rt.make_options(seed=1), 1500)
+    img, st = check_subset(load("mesh_scene"), rt.make_options(seed=1, cluster_culling=False), 1500)
     paths = 512 * 512 * 32
     assert st.paths == paths
     # the recorded algorithmic work of this configuration: 7 174 triangle tests per path

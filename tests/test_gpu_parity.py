@@ -85,3 +85,50 @@ def test_cat_glass_and_mirror_match_oracle(material):
     img, _ = dev.render(cam, opt)
     ref, _ = ob.render_image(desc, cam, ob.from_rt_options(opt))
     assert same_bits(img, ref), f"max abs diff {np.nanmax(np.abs(img - ref))}"
+
+
+# ---- exhaustive scan vs cluster culling -----------------------------------
+# make_options() turns cluster culling on, so every test above runs the culled
+# pipeline; the tests below pin the exhaustive scan (the reference's own loop)
+# and compare the two modes with each other at full size.
+
+@pytest.mark.parametrize("scene_name", ["mesh_scene", "simple"])
+@pytest.mark.parametrize("bbox", [True, False])
+def test_exhaustive_scan_cast_matches_oracle(scene_name, bbox):
+    s = load(scene_name)
+    desc, cam = s.describe()
+    dev = s.upload()
+    o, d = rays_for(None, 20000, 17)
+    opt = rt.make_options(bounding_box=bbox, cluster_culling=False)
+    t, sid, tid, abg = dev.cast(opt, o, d)
+    rt_, rsid, rtid, rabg = ob.cast(desc, ob.from_rt_options(opt), o, d)
+    assert np.array_equal(sid, rsid) and np.array_equal(tid, rtid)
+    assert same_bits(t, rt_)
+    assert same_bits(abg[rtid >= 0], rabg[rtid >= 0])
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_exhaustive_scan_render_matches_oracle_bitwise(mode):
+    indirect, aa, bbox = MODES[mode]
+    s = load("mesh_scene", 48, 40, 3)
+    desc, cam = s.describe()
+    opt = rt.make_options(indirect, aa, bbox, seed=5, cluster_culling=False)
+    img, st = s.upload().render(cam, opt)
+    ref, counters = ob.render_image(desc, cam, ob.from_rt_options(opt))
+    assert same_bits(img, ref)
+    if indirect or aa:
+        assert 0 < st.triangle_tests <= counters["triangle_tests"]
+
+
+def test_culled_and_exhaustive_frames_are_identical_at_full_size():
+    s = load("mesh_scene")
+    desc, cam = s.describe()
+    dev = s.upload()
+    a, sa = dev.render(cam, rt.make_options(seed=1, cluster_culling=True))
+    b, sb = dev.render(cam, rt.make_options(seed=1, cluster_culling=False))
+    differing = int((a.view(np.uint32) != b.view(np.uint32)).any(axis=2).sum())
+    print(f"culled {sa.triangle_tests / sa.paths:.0f} vs exhaustive {sb.triangle_tests / sb.paths:.0f} triangle tests per path; "
+          f"{differing} of {a.shape[0] * a.shape[1]} pixels differ")
+    assert differing == 0
+    assert sa.mesh_rays == sb.mesh_rays
+    assert sa.triangle_tests < 0.35 * sb.triangle_tests
