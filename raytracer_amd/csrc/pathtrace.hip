@@ -63,6 +63,9 @@ constexpr uint32_t kWavesPerBlock = kBlock / 64;
 constexpr uint32_t kChunkPairs = 256;       // triangle pairs per k_mesh job (512 triangles)
 constexpr uint32_t kMeshGrid = 256 * 8;     // persistent k_mesh grid: 8 workgroups per CU
 constexpr uint32_t kShards = 64;            // ray-queue shards = lanes of a wavefront
+// Every atomically updated counter sits on a 128-byte line of its own: atomics
+// to one line serialise, whatever word of it they touch.
+constexpr uint32_t kCountStride = 32;
 constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none)
 constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
 constexpr uint32_t kMaxLights = 64;
@@ -109,7 +112,7 @@ struct Work {
     unsigned long long* hit; // paths + paths*n_lights slots: (t bits << 32) | triangle
     float4* q_o;     // queued ray origin.xyz, hit slot as uint bits
     float4* q_d;     // queued ray direction.xyz, cut-off distance
-    uint32_t* q_count; // kShards counters per k_mesh launch of a batch
+    uint32_t* q_count; // kShards counters (kCountStride words apart) per k_mesh stage of a batch
     uint32_t shard_capacity; // queue entries reserved per shard
     // cluster culling: per stage slot, the queue positions of the rays that touch each cluster
     uint32_t* cl_count;      // n_clusters counters per slot
@@ -220,7 +223,7 @@ __device__ __forceinline__ void enqueue(const Work& w, uint32_t counter, bool wa
     const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
     const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&w.q_count[counter * kShards + shard], (uint32_t)__popcll(mask));
+    if (lane == leader) base = atomicAdd(&w.q_count[(counter * kShards + shard) * kCountStride], (uint32_t)__popcll(mask));
     base = __shfl(base, (int)leader);
     if (want) {
         const size_t at = (size_t)shard * w.shard_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
@@ -326,7 +329,7 @@ struct ShardMap {
 __device__ __forceinline__ ShardMap load_shard_map(const uint32_t* __restrict__ q_count) {
     ShardMap m;
     const uint32_t lane = __lane_id();
-    m.my_count = q_count[lane];
+    m.my_count = q_count[lane * kCountStride];
     const uint32_t my_blocks = (m.my_count + kBlock - 1) / kBlock;
     uint32_t incl = my_blocks;
 #pragma unroll
@@ -426,10 +429,6 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
 // reference's own rounding makes it accept a triangle for a ray that misses
 // the triangle by more than the padding (a grazing ray whose barycentrics are
 // rounding noise); rt_options.cluster_culling = 0 selects the exhaustive scan.
-
-// Counters of different clusters sit on different 128-byte lines: atomics to
-// one line serialise, whatever word of it they touch.
-constexpr uint32_t kCountStride = 32;
 
 // Slab test of a ray against padded cluster bounds, up to the ray's cut-off
 // distance.  fminf/fmaxf drop the NaN of 0 * inf (origin on a slab plane,
@@ -1023,7 +1022,7 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
         (rc = work_alloc(s, &s->w.thr, n_paths)) || (rc = work_alloc(s, &s->w.rad, n_paths)) ||
         (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
         (rc = work_alloc(s, &s->w.q_o, queue_entries)) || (rc = work_alloc(s, &s->w.q_d, queue_entries)) ||
-        (rc = work_alloc(s, &s->w.q_count, (size_t)n_counters * kShards)) ||
+        (rc = work_alloc(s, &s->w.q_count, (size_t)n_counters * kShards * kCountStride)) ||
         (rc = work_alloc(s, &s->w.cl_count, slots_cl * nc * kCountStride)) || (rc = work_alloc(s, &s->w.cl_first, slots_cl * (nc + 1))) ||
         (rc = work_alloc(s, &s->w.cl_list, nc * list_capacity))) {
         free_work(s);
@@ -1067,7 +1066,7 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
         HIP_TRY(hipEventRecord(e0, stream));
     }
     const f2* tri2 = reinterpret_cast<const f2*>(s->d.tri_pair);
-    const uint32_t* q_count = s->w.q_count + (size_t)counter * kShards;
+    const uint32_t* q_count = s->w.q_count + (size_t)counter * kShards * kCountStride;
     if (cull && s->d.n_clusters > 1) {
         const uint32_t nc = s->d.n_clusters;
         const uint32_t blocks_per_tile = s->w.list_capacity / kBlock;
@@ -1289,7 +1288,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         HIP_TRY(hipEventCreate(&t1));
         HIP_TRY(hipEventRecord(t0, stream));
     }
-    std::vector<uint32_t> counts((size_t)n_counters * kShards);
+    std::vector<uint32_t> counts((size_t)n_counters * kShards * kCountStride);
     uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
     uint32_t batches = 0;
 
@@ -1318,7 +1317,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
             if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), s->w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             uint64_t batch_rays = 0;
-            for (uint32_t c : counts) batch_rays += c;
+            for (size_t i = 0; i < counts.size(); i += kCountStride) batch_rays += counts[i];
             mesh_rays += batch_rays;
             if (cull) {
                 for (size_t i = 0; i < cl_words; i += kCountStride) tests += (uint64_t)cl_counts[i] * s->cluster_tris[(i / kCountStride) % s->d.n_clusters];
@@ -1416,7 +1415,7 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
     rc = RT_OK;
     do {
         if (hipMemcpy(d_a, a, 3 * (size_t)n * 4, hipMemcpyHostToDevice) || hipMemcpy(d_b, b, 3 * (size_t)n * 4, hipMemcpyHostToDevice) ||
-            hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(s->w.q_count, 0, 2 * kShards * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+            hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(s->w.q_count, 0, 2 * kShards * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, s->w, f, (const float*)d_a, (const float*)d_b, as_segments);
         const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
         if (cull && hipMemset(s->w.cl_count, 0, (size_t)2 * s->tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
