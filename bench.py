@@ -7,11 +7,16 @@ A step is one frame of the workload the headline metric is quoted on: the cat
 mesh scene (assets/scenes/mesh_scene.json, 3 954 triangles) at 512x512, 32
 samples per pixel, 5 bounces, indirect lighting + anti-aliasing + bounding box.
 The scene is resident in HBM before the timed region; every step renders the
-whole frame.  With N > 1 (one process per GPU, launched by torch.distributed.run)
-the 32 samples of every pixel are split over the ranks, each rank accumulates
-linear radiance for its sample range, the buffers are summed with one RCCL
-all-reduce and every rank resolves the image: total work is fixed (strong
-scaling).  Rank 0 prints one JSON line.
+whole frame in the library's default mode (cluster culling on).  With N > 1
+(one process per GPU, launched by torch.distributed.run) the 32 samples of
+every pixel are split over the ranks, each rank accumulates linear radiance for
+its sample range, the buffers are summed with one RCCL all-reduce and every
+rank resolves the image: total work is fixed (strong scaling).
+
+After the timed region rank 0 also times the exhaustive-scan mode (every
+queued ray against every triangle, the reference's own amount of work) and, at
+N = 1, the CPU oracle on a bounded sample of the same frame.  Rank 0 prints one
+JSON line.
 """
 import argparse
 import json
@@ -57,13 +62,48 @@ def cpu_baseline(desc, cam, opt, n_pixels_sample=65536):
     }
 
 
+class Meter:
+    """Sums the per-frame kernel statistics of the timed steps."""
+
+    def __init__(self):
+        self.mesh_ms = self.bin_ms = 0.0
+        self.launches = self.tests = self.frames = 0
+
+    def add(self, st):
+        if st is None:
+            return
+        self.mesh_ms += st.mesh_kernel_ms
+        self.bin_ms += st.bin_kernel_ms
+        self.launches += st.mesh_kernel_launches
+        self.tests += st.triangle_tests
+        self.frames += 1
+
+    def roofline(self, kernel, elapsed_ms, traffic):
+        achieved = self.tests * FLOP_PER_TRIANGLE_TEST / (self.mesh_ms * 1e-3) / 1e12 if self.mesh_ms > 0 else 0.0
+        return {
+            "bound": "valu",
+            "kernel": kernel,
+            "achieved": achieved,
+            "peak": PEAK_FP32_VECTOR_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+            "traffic": traffic,
+            "avg_launch_ms": self.mesh_ms / self.launches if self.launches else None,
+            "launches_per_step": self.launches / max(self.frames, 1),
+            "triangle_tests_per_step": self.tests / max(self.frames, 1),
+            "kernel_share_of_step": self.mesh_ms / elapsed_ms if elapsed_ms else None,
+            "binning_ms_per_step": self.bin_ms / max(self.frames, 1),
+        }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="mesh_scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exhaustive", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -79,64 +119,55 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import raytracer_amd as rt
+    from raytracer_amd.distributed import FrameRenderer
 
     rt.init(local_rank)
     scene = rt.Scene()
     scene.load_scene(os.path.join(rt.ASSETS, "scenes", args.scene + ".json"))
     desc, cam = scene.describe()
     dev = scene.upload()
-    opt = rt.make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, profile=True)
     n_pixels = cam.width * cam.height
     spp = cam.num_rays
-
-    from raytracer_amd.distributed import FrameRenderer
-
-    renderer = FrameRenderer(dev, cam, opt, want_stats=True)
-
-    mesh_ms = 0.0
-    mesh_launches = 0
-    tri_tests = 0
-
-    def step(timed):
-        nonlocal mesh_ms, mesh_launches, tri_tests
-        renderer.render()
-        st = renderer.last_stats
-        if timed and st is not None:
-            mesh_ms += st.mesh_kernel_ms
-            mesh_launches += st.mesh_kernel_launches
-            tri_tests += st.triangle_tests
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def run(cluster_culling, steps, warmup):
+        opt = rt.make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, profile=True,
+                              cluster_culling=cluster_culling)
+        renderer = FrameRenderer(dev, cam, opt, want_stats=True)
+        meter = Meter()
+        for _ in range(warmup):
+            renderer.render()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            renderer.render()
+            meter.add(renderer.last_stats)
+        fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), meter, opt
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, meter, opt = run(True, args.steps, args.warmup)
+    exhaustive = None
+    if not args.no_exhaustive:
+        ex_steps = max(1, min(args.steps, 5))
+        ex_elapsed, ex_meter, _ = run(False, ex_steps, 1)
+        exhaustive = (ex_elapsed, ex_meter, ex_steps)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_pixels * spp / (elapsed / args.steps) / 1e6
-        # dominant kernel: k_mesh.  Algorithmic flops of the launches of rank 0
-        # (47 per ray-triangle test the kernel executed) over their summed
-        # duration, measured with HIP events on the launch stream.
-        achieved = (tri_tests * FLOP_PER_TRIANGLE_TEST) / (mesh_ms * 1e-3) / 1e12 if mesh_ms > 0 else 0.0
-        traffic = None
+        traffic = {}
         tpath = os.path.join(ROOT, "profiles", "mesh_kernel_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                traffic = json.load(f)
         line = {
             "metric": "Mpaths/s, cat mesh 512x512 32spp 5-bounce indirect+AA+bbox",
             "value": value,
@@ -154,22 +185,25 @@ def main():
             "config": {
                 "workload": f"{args.scene}.json {cam.width}x{cam.height} {spp}spp depth5 indirect+AA+bbox",
                 "triangles": int(desc.n_triangles),
+                "mode": "cluster culling on (library default; image bit-identical to the exhaustive scan)",
                 "parallelism": f"spp-split x{world} + RCCL all-reduce of linear radiance" if world > 1 else "single GPU",
             },
-            "roofline": {
-                "bound": "valu",
-                "kernel": "k_mesh",
-                "achieved": achieved,
-                "peak": PEAK_FP32_VECTOR_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                "traffic": traffic,
-                "avg_launch_ms": mesh_ms / mesh_launches if mesh_launches else None,
-                "launches_per_step": mesh_launches / args.steps,
-                "triangle_tests_per_step": tri_tests / args.steps,
-                "kernel_share_of_step": mesh_ms / (elapsed * 1e3),
-            },
+            # dominant kernel of the timed region: k_mesh_clusters.  Algorithmic
+            # flops of rank 0's launches (47 per ray-triangle test executed)
+            # over their summed duration, from HIP events on the launch stream.
+            "roofline": meter.roofline("k_mesh_clusters", elapsed * 1e3, traffic.get("k_mesh_clusters_hbm_bytes_per_launch")),
         }
+        if exhaustive is not None:
+            ex_elapsed, ex_meter, ex_steps = exhaustive
+            line["exhaustive_scan"] = {
+                "note": "cluster_culling=0: every queued ray against every triangle, the reference's own work "
+                        "(7 175 triangle tests per path)",
+                "steps": ex_steps,
+                "ms_per_step": ex_elapsed / ex_steps * 1e3,
+                "value": n_pixels * spp / (ex_elapsed / ex_steps) / 1e6,
+                "unit": "Mpaths/s",
+                "roofline": ex_meter.roofline("k_mesh", ex_elapsed * 1e3, traffic.get("hbm_bytes_per_launch")),
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(desc, cam, opt)
         print(json.dumps(line), flush=True)

@@ -93,12 +93,13 @@ typedef struct rt_options {
 /* Work executed by the most recent render / accumulate call. */
 typedef struct rt_stats {
     double gpu_ms;             /* first kernel start -> last kernel end        */
-    double mesh_kernel_ms;     /* summed over launches (profile != 0 only)     */
+    double mesh_kernel_ms;     /* triangle kernel, summed over launches (profile != 0 only) */
+    double bin_kernel_ms;      /* cluster binning + planning kernels (profile != 0 only)   */
     uint32_t mesh_kernel_launches;
     uint32_t batches;
     uint64_t paths;
     uint64_t mesh_rays;        /* rays that walked the triangle list           */
-    uint64_t triangle_tests;   /* mesh_rays * n_triangles                      */
+    uint64_t triangle_tests;   /* ray-triangle tests the triangle kernel executed */
     uint64_t sphere_casts;     /* casts tested against every sphere            */
 } rt_stats;
 

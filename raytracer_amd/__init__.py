@@ -61,7 +61,7 @@ class Options(C.Structure):
 class Stats(C.Structure):
     """rt_stats"""
     _fields_ = [
-        ("gpu_ms", C.c_double), ("mesh_kernel_ms", C.c_double),
+        ("gpu_ms", C.c_double), ("mesh_kernel_ms", C.c_double), ("bin_kernel_ms", C.c_double),
         ("mesh_kernel_launches", C.c_uint32), ("batches", C.c_uint32),
         ("paths", C.c_uint64), ("mesh_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
         ("sphere_casts", C.c_uint64),

@@ -915,6 +915,7 @@ struct rt_scene {
     std::vector<uint32_t> cluster_tris;  // triangles per culling cluster
     // profiling events
     std::vector<hipEvent_t> events;
+    std::vector<char> event_tags;
 };
 
 namespace {
@@ -1057,14 +1058,17 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
 // the exhaustive scan or through the cluster lists.
 int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile, bool cull) {
     if (s->d.n_triangles == 0) return RT_OK;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (profile) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        s->events.push_back(e0);
-        s->events.push_back(e1);
-        HIP_TRY(hipEventRecord(e0, stream));
-    }
+    // profiling marks: 'B' binning starts, 'M' triangle kernel starts, 'E' it ended
+    auto mark = [&](char tag) -> int {
+        if (!profile) return RT_OK;
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        s->events.push_back(e);
+        s->event_tags.push_back(tag);
+        HIP_TRY(hipEventRecord(e, stream));
+        return RT_OK;
+    };
+    int rc;
     const f2* tri2 = reinterpret_cast<const f2*>(s->d.tri_pair);
     const uint32_t* q_count = s->w.q_count + (size_t)counter * kShards * kCountStride;
     if (cull && s->d.n_clusters > 1) {
@@ -1074,20 +1078,24 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
             const size_t slot = (size_t)counter * s->tiles + tile;
             uint32_t* cl_count = s->w.cl_count + slot * nc * kCountStride;
             uint32_t* cl_first = s->w.cl_first + slot * (nc + 1);
+            if ((rc = mark('B')) != RT_OK) return rc;
             hipLaunchKernelGGL(k_bin, dim3(kMeshGrid), dim3(kBlock), 0, stream, s->d, (const float4*)s->w.q_o, (const float4*)s->w.q_d,
                                q_count, s->w.shard_capacity, tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list,
                                s->w.list_capacity);
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cl_count, nc, cl_first);
+            if ((rc = mark('M')) != RT_OK) return rc;
             hipLaunchKernelGGL(k_mesh_clusters, dim3(kMeshGrid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
                                s->d.cluster_pairs, (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)cl_count,
                                (const uint32_t*)cl_first, (const uint32_t*)s->w.cl_list, s->w.list_capacity, s->w.hit);
+            if ((rc = mark('E')) != RT_OK) return rc;
         }
     } else {
+        if ((rc = mark('M')) != RT_OK) return rc;
         hipLaunchKernelGGL(k_mesh, dim3(kMeshGrid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles,
                            (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity, s->w.hit);
+        if ((rc = mark('E')) != RT_OK) return rc;
     }
     HIP_TRY(hipGetLastError());
-    if (profile) HIP_TRY(hipEventRecord(e1, stream));
     return RT_OK;
 }
 
@@ -1282,6 +1290,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
     uint64_t tests = 0;
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     s->events.clear();
+    s->event_tags.clear();
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (stats) {
         HIP_TRY(hipEventCreate(&t0));
@@ -1334,11 +1343,16 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         stats->gpu_ms = ms;
         (void)hipEventDestroy(t0);
         (void)hipEventDestroy(t1);
-        for (size_t i = 0; i + 1 < s->events.size(); i += 2) {
+        for (size_t i = 0; i + 1 < s->events.size(); i++) {
+            if (s->event_tags[i] == 'E') continue;
             float k = 0.f;
             HIP_TRY(hipEventElapsedTime(&k, s->events[i], s->events[i + 1]));
-            stats->mesh_kernel_ms += k;
-            stats->mesh_kernel_launches++;
+            if (s->event_tags[i] == 'B') {
+                stats->bin_kernel_ms += k;
+            } else {
+                stats->mesh_kernel_ms += k;
+                stats->mesh_kernel_launches++;
+            }
         }
         stats->batches = batches;
         stats->paths = paths;
