@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -94,6 +95,7 @@ struct DeviceScene {
                               // (triangles are stored in Morton order of their centroids)
     const float4* cl_min;     // padded bounds of each cluster of cluster_pairs consecutive pairs
     const float4* cl_max;
+    const float2* cl_pair;    // 6 per PAIR of clusters (2k, 2k+1): lo.x lo.y lo.z hi.x hi.y hi.z
     const float4* tri_shade;  // 3 per triangle: n0.xyz material | n1.xyz - | n2.xyz -
     const float4* box_min;
     const float4* box_max;
@@ -479,6 +481,67 @@ __global__ __launch_bounds__(kBlock) void k_bin(DeviceScene sc, const float4* __
             const bool touch = active && touches(sc.cl_min[c], sc.cl_max[c], o4, ix, iy, iz, d4.w);
             const unsigned long long mask = __ballot(touch);
             if (touch) cl_list[(size_t)c * list_capacity + slot[c][wave] + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL))] = at;
+        }
+        __syncthreads();
+    }
+}
+
+// The same binning for meshes of at most 64 clusters, in one pass over the
+// clusters: a lane keeps the clusters its ray touches as a 64-bit mask, the
+// workgroup counts per cluster in LDS, reserves list space with one atomic per
+// cluster, and every lane then walks the set bits of its mask.  Two clusters
+// are tested per iteration; the slab parameters come from packed FMAs
+// (t = bound * (1/u) - origin * (1/u)), which is only a filter and need not
+// follow the reference's rounding.
+__global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ cl_pair, uint32_t n_clusters,
+                                                  const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                  const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
+                                                  uint32_t first_block, uint32_t blocks_in_tile,
+                                                  uint32_t* __restrict__ cl_count, uint32_t* __restrict__ cl_list, uint32_t list_capacity) {
+    __shared__ uint32_t slot[64]; // counts, then next free list position
+    const ShardMap map = load_shard_map(q_count);
+    const uint32_t end = min(first_block + blocks_in_tile, map.n_ray_blocks);
+    const uint32_t lane = __lane_id();
+    const uint32_t n_pairs = (n_clusters + 1) / 2;
+    for (uint32_t ray_block = first_block + blockIdx.x; ray_block < end; ray_block += gridDim.x) {
+        if (threadIdx.x < 64) slot[threadIdx.x] = 0;
+        __syncthreads();
+        bool active;
+        const uint32_t at = ray_position(map, ray_block, shard_capacity, active);
+        const float4 o4 = q_o[at];
+        const float4 d4 = q_d[at];
+        const float ix = 1.f / d4.x, iy = 1.f / d4.y, iz = 1.f / d4.z; // +-inf for an axis-parallel ray
+        const float ox = o4.x * ix, oy = o4.y * iy, oz = o4.z * iz;
+        unsigned long long mine = 0;
+        for (uint32_t k = 0; k < n_pairs; k++) {
+            const f2* __restrict__ b = cl_pair + 6 * (size_t)k;
+            // NaN (inf - inf on an axis-parallel ray) is dropped by fminf/fmaxf: errs towards "touches"
+            const f2 ax = __builtin_elementwise_fma(b[0], (f2)(ix), (f2)(-ox)), bx = __builtin_elementwise_fma(b[3], (f2)(ix), (f2)(-ox));
+            const f2 ay = __builtin_elementwise_fma(b[1], (f2)(iy), (f2)(-oy)), by = __builtin_elementwise_fma(b[4], (f2)(iy), (f2)(-oy));
+            const f2 az = __builtin_elementwise_fma(b[2], (f2)(iz), (f2)(-oz)), bz = __builtin_elementwise_fma(b[5], (f2)(iz), (f2)(-oz));
+            const float in0 = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
+            const float out0 = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
+            const float in1 = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
+            const float out1 = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
+            const bool t0 = active && out0 >= fmaxf(in0, 0.f) && in0 <= d4.w;
+            const bool t1 = active && out1 >= fmaxf(in1, 0.f) && in1 <= d4.w;
+            const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1);
+            if (lane == 0) {
+                if (m0) atomicAdd(&slot[2 * k], (uint32_t)__popcll(m0));
+                if (m1) atomicAdd(&slot[2 * k + 1], (uint32_t)__popcll(m1));
+            }
+            mine |= ((unsigned long long)t0 << (2 * k)) | ((unsigned long long)t1 << (2 * k + 1));
+        }
+        __syncthreads();
+        if (threadIdx.x < n_clusters) {
+            const uint32_t total = slot[threadIdx.x];
+            slot[threadIdx.x] = total ? atomicAdd(&cl_count[threadIdx.x * kCountStride], total) : 0;
+        }
+        __syncthreads();
+        while (mine) {
+            const uint32_t c = (uint32_t)__ffsll((long long)mine) - 1u;
+            mine &= mine - 1;
+            cl_list[(size_t)c * list_capacity + atomicAdd(&slot[c], 1u)] = at;
         }
         __syncthreads();
     }
@@ -1079,9 +1142,14 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
             uint32_t* cl_count = s->w.cl_count + slot * nc * kCountStride;
             uint32_t* cl_first = s->w.cl_first + slot * (nc + 1);
             if ((rc = mark('B')) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_bin, dim3(kMeshGrid), dim3(kBlock), 0, stream, s->d, (const float4*)s->w.q_o, (const float4*)s->w.q_d,
-                               q_count, s->w.shard_capacity, tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list,
-                               s->w.list_capacity);
+            if (nc <= 64)
+                hipLaunchKernelGGL(k_bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.cl_pair), nc,
+                                   (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
+                                   tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list, s->w.list_capacity);
+            else
+                hipLaunchKernelGGL(k_bin, dim3(kMeshGrid), dim3(kBlock), 0, stream, s->d, (const float4*)s->w.q_o, (const float4*)s->w.q_d,
+                                   q_count, s->w.shard_capacity, tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list,
+                                   s->w.list_capacity);
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cl_count, nc, cl_first);
             if ((rc = mark('M')) != RT_OK) return rc;
             hipLaunchKernelGGL(k_mesh_clusters, dim3(kMeshGrid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
@@ -1205,6 +1273,10 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     // Clusters of consecutive pairs and their bounds, padded by 0.05 plus a
     // thousandth of the cluster's diagonal.
     uint32_t cluster_pairs = kClusterPairs;
+    if (const char* env = std::getenv("RT_AMD_CLUSTER_PAIRS")) { // tuning / test knob: pairs per cluster
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= 4096) cluster_pairs = (uint32_t)v;
+    }
     while ((n_pairs + cluster_pairs - 1) / cluster_pairs > kMaxClusters) cluster_pairs *= 2;
     const uint32_t n_clusters = (uint32_t)((n_pairs + cluster_pairs - 1) / cluster_pairs);
     std::vector<float4> cl_min(n_clusters), cl_max(n_clusters);
@@ -1227,6 +1299,18 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
         cl_min[c] = make_float4(lo[0] - pad, lo[1] - pad, lo[2] - pad, 0.f);
         cl_max[c] = make_float4(hi[0] + pad, hi[1] + pad, hi[2] + pad, 0.f);
     }
+    // the same bounds, two clusters per entry for k_bin64; an odd count is
+    // padded with an inverted box no ray can touch
+    std::vector<float2> cl_pair(6 * (((size_t)n_clusters + 1) / 2), make_float2(1e30f, 1e30f));
+    for (uint32_t c = 0; c < ((n_clusters + 1) / 2) * 2; c++) {
+        const bool real = c < n_clusters;
+        const float v[6] = {real ? cl_min[c].x : 1e30f, real ? cl_min[c].y : 1e30f, real ? cl_min[c].z : 1e30f,
+                            real ? cl_max[c].x : -1e30f, real ? cl_max[c].y : -1e30f, real ? cl_max[c].z : -1e30f};
+        for (int k = 0; k < 6; k++) {
+            float2& dst = cl_pair[6 * (size_t)(c / 2) + k];
+            if (c & 1) dst.y = v[k]; else dst.x = v[k];
+        }
+    }
     std::vector<float4> box_min(d->n_boxes), box_max(d->n_boxes), light(d->n_lights);
     for (uint32_t i = 0; i < d->n_boxes; i++) {
         box_min[i] = make_float4(d->box_min[3 * i], d->box_min[3 * i + 1], d->box_min[3 * i + 2], 0.f);
@@ -1246,7 +1330,7 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     if ((rc = upload(s, sphere, &s->d.sphere)) || (rc = upload(s, sphere_mat, &s->d.sphere_mat)) ||
         (rc = upload(s, mat_color, &s->d.mat_color)) || (rc = upload(s, mat_ior, &s->d.mat_ior)) ||
         (rc = upload(s, geom, &s->d.tri_geom)) || (rc = upload(s, pair, &s->d.tri_pair)) || (rc = upload(s, orig, &s->d.tri_orig)) ||
-        (rc = upload(s, cl_min, &s->d.cl_min)) || (rc = upload(s, cl_max, &s->d.cl_max)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
+        (rc = upload(s, cl_min, &s->d.cl_min)) || (rc = upload(s, cl_max, &s->d.cl_max)) || (rc = upload(s, cl_pair, &s->d.cl_pair)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
         (rc = upload(s, box_min, &s->d.box_min)) || (rc = upload(s, box_max, &s->d.box_max)) ||
         (rc = upload(s, light, &s->d.light))) {
         rt_scene_free(s);

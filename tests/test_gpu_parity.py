@@ -132,3 +132,21 @@ def test_culled_and_exhaustive_frames_are_identical_at_full_size():
     assert differing == 0
     assert sa.mesh_rays == sb.mesh_rays
     assert sa.triangle_tests < 0.35 * sb.triangle_tests
+
+
+@pytest.mark.parametrize("pairs", ["4", "8", "64", "1000"])
+def test_other_cluster_sizes_give_the_same_image(pairs, monkeypatch):
+    """4 and 8 pairs per cluster give the cat more than 64 clusters (the general binning kernel),
+    1000 gives two clusters."""
+    monkeypatch.setenv("RT_AMD_CLUSTER_PAIRS", pairs)
+    s = variant("mesh_scene", "glass", 72, 56, 3)
+    desc, cam = s.describe()
+    dev = s.upload()
+    opt = rt.make_options(seed=23)
+    img, st = dev.render(cam, opt)
+    ref, _ = ob.render_image(desc, cam, ob.from_rt_options(opt))
+    assert same_bits(img, ref)
+    o, d = rays_for(None, 30000, 5)
+    t, sid, tid, abg = dev.cast(opt, o, d)
+    rt_, rsid, rtid, rabg = ob.cast(desc, ob.from_rt_options(opt), o, d)
+    assert np.array_equal(tid, rtid) and same_bits(t, rt_)
