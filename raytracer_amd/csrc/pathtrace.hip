@@ -275,6 +275,25 @@ __device__ __forceinline__ void exact_hit(float nb, float ng, float d, float ao_
     }
 }
 
+// A lane the division-free test could not reject.  `lo` is the smallest of the
+// approximate alpha, beta, gamma (each within 1e-6 of the exact value when the
+// point is inside).  lo >= 1e-5 means the reference's exact values are all
+// positive, so the hit is accepted without computing them, and only its
+// distance needs the IEEE division -- and not even that when the approximate
+// distance (relative error < 4e-7) is negative or clearly beyond the best so
+// far.  Anything closer to an edge, and any NaN, takes exact_hit.
+__device__ __forceinline__ void candidate(float lo, float nb, float ng, float d, float rcp, float ao_dot_n, uint32_t index,
+                                          float& best, int& best_i) {
+    if (lo >= 1e-5f) {
+        const float t_ = ao_dot_n * rcp;
+        if (t_ > best * 1.000002f || t_ < 0.f) return;
+        const float t = ao_dot_n / d;
+        if (t > 0 && (t < best || (t == best && best_i >= 0 && (int)index < best_i))) { best = t; best_i = (int)index; }
+    } else {
+        exact_hit(nb, ng, d, ao_dot_n, index, best, best_i);
+    }
+}
+
 // Twelve packed values of one triangle pair: A.xyz, e1.xyz, e2.xyz, N.xyz.
 struct PairData {
     f2 v[12];
@@ -317,8 +336,8 @@ __device__ __forceinline__ void test_pair(const PairData& p, const uint32_t* __r
     const float lo1 = fminf(fminf(a_.y, b_.y), g_.y);
     if (!(lo0 < -1e-5f) || !(lo1 < -1e-5f)) {
         const f2 aon = (aox * Nx + aoy * Ny) + aoz * Nz;
-        if (!(lo0 < -1e-5f)) exact_hit(nb.x, ng.x, d.x, aon.x, orig[0], best, best_i);
-        if (!(lo1 < -1e-5f)) exact_hit(nb.y, ng.y, d.y, aon.y, orig[1], best, best_i);
+        if (!(lo0 < -1e-5f)) candidate(lo0, nb.x, ng.x, d.x, rcp.x, aon.x, orig[0], best, best_i);
+        if (!(lo1 < -1e-5f)) candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, orig[1], best, best_i);
     }
 }
 
