@@ -114,14 +114,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    # RT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     import raytracer_amd as rt
     from raytracer_amd.distributed import FrameRenderer
 
-    rt.init(local_rank)
+    rt.init(device)
     scene = rt.Scene()
     scene.load_scene(os.path.join(rt.ASSETS, "scenes", args.scene + ".json"))
     desc, cam = scene.describe()
@@ -143,7 +149,11 @@ def main():
             renderer.render()
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            # kernel timing events and counter read-back (one stream sync) on every 4th
+            # timed step only; the other steps just enqueue
+            renderer.want_stats = i % 4 == 0
+            renderer.last_stats = None
             renderer.render()
             meter.add(renderer.last_stats)
         fence()

@@ -670,13 +670,19 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             // r1 < 0.77 has radius > 0.722 and max(|cos|,|sin|) >= 0.7071, so
             // one component exceeds 0.5: it is rejected without evaluating the
             // logarithm and the trigonometric pair.
+            // Such draws are skipped in a tight inner loop (one hash per draw)
+            // so that the lanes of a wavefront meet again for the expensive
+            // evaluation of a plausible draw.
             dx = 1.f;
             dy = 1.f;
             while (fabsf(dx) > 0.5f || fabsf(dy) > 0.5f) {
-                const float r1 = rt_rng_uniform(key, dim);
+                float r1 = rt_rng_uniform(key, dim);
+                while (r1 < 0.77f) {
+                    dim += 2;
+                    r1 = rt_rng_uniform(key, dim);
+                }
                 const float r2 = rt_rng_uniform(key, dim + 1);
                 dim += 2;
-                if (r1 < 0.77f) continue;
                 const float radius = sqrtf(-2 * rt_logf(r1));
                 const float angle = (float)(2 * M_PI * (double)r2);
                 float sn, cs;
@@ -996,8 +1002,9 @@ struct rt_scene {
     uint32_t tiles = 1;                  // cluster-list tiles per k_mesh stage
     std::vector<uint32_t> cluster_tris;  // triangles per culling cluster
     // profiling events
-    std::vector<hipEvent_t> events;
-    std::vector<char> event_tags;
+    std::vector<hipEvent_t> events;   // pool, reused by every call
+    std::vector<char> event_tags;     // tag of the events in use, in record order
+    hipEvent_t frame_begin = nullptr, frame_end = nullptr;
 };
 
 namespace {
@@ -1143,11 +1150,13 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
     // profiling marks: 'B' binning starts, 'M' triangle kernel starts, 'E' it ended
     auto mark = [&](char tag) -> int {
         if (!profile) return RT_OK;
-        hipEvent_t e = nullptr;
-        HIP_TRY(hipEventCreate(&e));
-        s->events.push_back(e);
+        if (s->event_tags.size() == s->events.size()) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            s->events.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(s->events[s->event_tags.size()], stream));
         s->event_tags.push_back(tag);
-        HIP_TRY(hipEventRecord(e, stream));
         return RT_OK;
     };
     int rc;
@@ -1364,6 +1373,8 @@ extern "C" int rt_scene_free(rt_scene* s) {
     free_work(s);
     for (void* p : s->allocations) (void)hipFree(p);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    if (s->frame_begin) (void)hipEventDestroy(s->frame_begin);
+    if (s->frame_end) (void)hipEventDestroy(s->frame_end);
     delete s;
     return RT_OK;
 }
@@ -1391,14 +1402,11 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
     const size_t cl_words = cull ? (size_t)n_counters * s->tiles * s->d.n_clusters * kCountStride : 0;
     std::vector<uint32_t> cl_counts(cl_words);
     uint64_t tests = 0;
-    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
-    s->events.clear();
     s->event_tags.clear();
-    hipEvent_t t0 = nullptr, t1 = nullptr;
     if (stats) {
-        HIP_TRY(hipEventCreate(&t0));
-        HIP_TRY(hipEventCreate(&t1));
-        HIP_TRY(hipEventRecord(t0, stream));
+        if (!s->frame_begin) HIP_TRY(hipEventCreate(&s->frame_begin));
+        if (!s->frame_end) HIP_TRY(hipEventCreate(&s->frame_end));
+        HIP_TRY(hipEventRecord(s->frame_begin, stream));
     }
     std::vector<uint32_t> counts((size_t)n_counters * kShards * kCountStride);
     uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
@@ -1439,14 +1447,12 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         }
     }
     if (stats) {
-        HIP_TRY(hipEventRecord(t1, stream));
-        HIP_TRY(hipEventSynchronize(t1));
+        HIP_TRY(hipEventRecord(s->frame_end, stream));
+        HIP_TRY(hipEventSynchronize(s->frame_end));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+        HIP_TRY(hipEventElapsedTime(&ms, s->frame_begin, s->frame_end));
         stats->gpu_ms = ms;
-        (void)hipEventDestroy(t0);
-        (void)hipEventDestroy(t1);
-        for (size_t i = 0; i + 1 < s->events.size(); i++) {
+        for (size_t i = 0; i + 1 < s->event_tags.size(); i++) {
             if (s->event_tags[i] == 'E') continue;
             float k = 0.f;
             HIP_TRY(hipEventElapsedTime(&k, s->events[i], s->events[i + 1]));
