@@ -78,7 +78,7 @@ class Meter:
         self.tests += st.triangle_tests
         self.frames += 1
 
-    def roofline(self, kernel, elapsed_ms, traffic):
+    def roofline(self, kernel, step_ms, traffic):
         achieved = self.tests * FLOP_PER_TRIANGLE_TEST / (self.mesh_ms * 1e-3) / 1e12 if self.mesh_ms > 0 else 0.0
         return {
             "bound": "valu",
@@ -91,7 +91,7 @@ class Meter:
             "avg_launch_ms": self.mesh_ms / self.launches if self.launches else None,
             "launches_per_step": self.launches / max(self.frames, 1),
             "triangle_tests_per_step": self.tests / max(self.frames, 1),
-            "kernel_share_of_step": self.mesh_ms / elapsed_ms if elapsed_ms else None,
+            "kernel_share_of_step": self.mesh_ms / max(self.frames, 1) / step_ms if step_ms else None,
             "binning_ms_per_step": self.bin_ms / max(self.frames, 1),
         }
 
@@ -201,7 +201,7 @@ def main():
             # dominant kernel of the timed region: k_mesh_clusters.  Algorithmic
             # flops of rank 0's launches (47 per ray-triangle test executed)
             # over their summed duration, from HIP events on the launch stream.
-            "roofline": meter.roofline("k_mesh_clusters", elapsed * 1e3, traffic.get("k_mesh_clusters_hbm_bytes_per_launch")),
+            "roofline": meter.roofline("k_mesh_clusters", ms_per_step, traffic.get("k_mesh_clusters_hbm_bytes_per_launch")),
         }
         if exhaustive is not None:
             ex_elapsed, ex_meter, ex_steps = exhaustive
@@ -212,7 +212,7 @@ def main():
                 "ms_per_step": ex_elapsed / ex_steps * 1e3,
                 "value": n_pixels * spp / (ex_elapsed / ex_steps) / 1e6,
                 "unit": "Mpaths/s",
-                "roofline": ex_meter.roofline("k_mesh", ex_elapsed * 1e3, traffic.get("hbm_bytes_per_launch")),
+                "roofline": ex_meter.roofline("k_mesh", ex_elapsed / ex_steps * 1e3, traffic.get("hbm_bytes_per_launch")),
             }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(desc, cam, opt)

@@ -135,6 +135,15 @@ int rt_accumulate(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
                   void* stream, rt_stats* stats);
 int rt_resolve(const float* d_sum, uint32_t n_pixels, float* d_out_rgb, void* stream);
 
+/* Replaces the reference's progress bar (src/raytrace.cu:601-627, a mapped
+ * counter the host polls while the kernel runs).  A frame is rendered in
+ * batches of at most 2^24 paths; when a callback is set, rt_accumulate and
+ * rt_render wait for each batch and then call fn(paths_done, paths_total,
+ * user) on the calling thread.  fn == NULL removes it (the default: batches
+ * are only enqueued). */
+typedef void (*rt_progress_fn)(uint64_t paths_done, uint64_t paths_total, void* user);
+int rt_set_progress(rt_scene* scene, rt_progress_fn fn, void* user);
+
 /* Per-function entry points for known-answer tests.
  * rt_cast = get_intersection (src/raytrace.cu:179-216) for n rays given as
  * host arrays; out_t is +inf on a miss, ids are -1 when that kind is not
@@ -169,6 +178,22 @@ int rt_host_scene_set_options(rt_host_scene* s, const rt_options* opt);
  * reference (src/scene.cu:214-220) and writes an RGB PNG.  png_path may be
  * NULL to skip the file. */
 int rt_host_scene_render(rt_host_scene* s, const char* png_path, size_t seed);
+/* The frame loop the reference's README describes (README.md:24: move the
+ * camera with rotate_camera / transform_camera between calls of
+ * Scene::render and pass the frame number as the seed).  Frame i (0-based)
+ * is drawn after i applications of rotate_step (degrees) and move_step, with
+ * seed first_seed + i, into the file named by `pattern` (a printf pattern
+ * with one integer conversion, e.g. "out/frame_%04d.png"; ".pfm" selects a
+ * float image instead of a PNG).  Only frames i = first, first + stride, ...
+ * are rendered (one process per GPU: first = rank, stride = number of
+ * ranks); the camera still takes every step.  The scene stays on the device
+ * for the whole sequence and files are encoded by `writers` host threads
+ * while the next frame renders.  out_seconds (may be NULL) receives the wall
+ * time of the loop including the last file. */
+int rt_host_scene_render_frames(rt_host_scene* s, const char* pattern, size_t first_seed,
+                                uint32_t n_frames, const float rotate_step[3],
+                                const float move_step[3], uint32_t first, uint32_t stride,
+                                uint32_t writers, double* out_seconds);
 /* Borrowed views, valid until the scene is modified or destroyed. */
 int rt_host_scene_describe(rt_host_scene* s, rt_scene_desc* out_desc, rt_camera* out_cam);
 const float* rt_host_scene_image(rt_host_scene* s, uint32_t* out_width, uint32_t* out_height);
@@ -176,6 +201,10 @@ const float* rt_host_scene_image(rt_host_scene* s, uint32_t* out_width, uint32_t
 /* Encodes an 8-bit RGB image as PNG (the job stbi_write_png does in the
  * reference, src/scene.cu:221). */
 int rt_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb);
+/* Writes the unclamped float image (3 * width * height floats, row 0 on top,
+ * the layout rt_render returns) as a little-endian colour PFM, for
+ * convergence studies the reference's 8-bit PNG cannot serve. */
+int rt_write_pfm(const char* path, uint32_t width, uint32_t height, const float* rgb);
 
 #ifdef __cplusplus
 }

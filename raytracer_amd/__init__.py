@@ -21,6 +21,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 ASSETS = os.path.join(REPO_ROOT, "assets")
 
 RT_OK = 0
+RT_ERR_INVALID, RT_ERR_DEVICE, RT_ERR_IO, RT_ERR_PARSE, RT_ERR_NOMEM = -1, -2, -3, -4, -5
 DIFFUSE, MIRROR, GLASS = 0, 1, 2
 
 _f32p = C.POINTER(C.c_float)
@@ -104,6 +105,9 @@ def _preload_torch_hip_runtime() -> None:
             pass
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_uint64, C.c_uint64, C.c_void_p)
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -135,6 +139,10 @@ def _load() -> C.CDLL:
         "rt_host_scene_render": [vp, C.c_char_p, C.c_size_t],
         "rt_host_scene_describe": [vp, C.POINTER(SceneDesc), C.POINTER(Camera)],
         "rt_write_png": [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)],
+        "rt_write_pfm": [C.c_char_p, C.c_uint32, C.c_uint32, _f32p],
+        "rt_set_progress": [vp, PROGRESS_FN, vp],
+        "rt_host_scene_render_frames": [vp, C.c_char_p, C.c_size_t, C.c_uint32, _f32p, _f32p, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.POINTER(C.c_double)],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -156,7 +164,7 @@ EXPORTS = [
     "rt_host_scene_set_camera_intrinsics", "rt_host_scene_rotate_camera", "rt_host_scene_transform_camera",
     "rt_host_scene_set_num_rays", "rt_host_scene_add_sphere", "rt_host_scene_add_object", "rt_host_scene_add_light",
     "rt_host_scene_set_options", "rt_host_scene_render", "rt_host_scene_describe", "rt_host_scene_image",
-    "rt_write_png",
+    "rt_write_png", "rt_write_pfm", "rt_set_progress", "rt_host_scene_render_frames",
 ]
 
 
@@ -268,6 +276,11 @@ class DeviceScene:
                                  C.c_void_p(stream), C.byref(st) if st is not None else None))
         return st
 
+    def set_progress(self, callback) -> None:
+        """callback(paths_done, paths_total) after every finished batch of a frame; None removes it."""
+        self._progress = PROGRESS_FN(lambda done, total, _user: callback(done, total)) if callback else PROGRESS_FN()
+        _check(lib.rt_set_progress(self._h, self._progress, None))
+
     def cast(self, opt: Options, origins, dirs):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
@@ -342,6 +355,7 @@ class Scene:
     def describe(self) -> Tuple[SceneDesc, Camera]:
         d, c = SceneDesc(), Camera()
         _check(lib.rt_host_scene_describe(self._h, C.byref(d), C.byref(c)))
+        d._owner = self  # the pointers refer to this scene's arrays: keep it alive with the view
         return d, c
 
     def arrays(self) -> dict:
@@ -355,6 +369,18 @@ class Scene:
         p = lib.rt_host_scene_image(self._h, C.byref(w), C.byref(h))
         return np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
 
+    def render_frames(self, pattern: Optional[str], first_seed: int, n_frames: int, rotate_step=(0, 0, 0),
+                      move_step=(0, 0, 0), first: int = 0, stride: int = 1, writers: int = 4) -> float:
+        """Scene::render_frames: frame i after i camera steps, seed first_seed + i, file pattern % i.
+
+        One process per GPU renders its share with first=rank, stride=world size.  Returns seconds."""
+        _check(lib.rt_host_scene_set_options(self._h, C.byref(self.options)))
+        seconds = C.c_double()
+        _check(lib.rt_host_scene_render_frames(self._h, os.fsencode(pattern) if pattern else None, first_seed, n_frames,
+                                               _vec3(rotate_step), _vec3(move_step), first, stride, writers,
+                                               C.byref(seconds)))
+        return seconds.value
+
     def upload(self) -> DeviceScene:
         return DeviceScene(self.describe()[0])
 
@@ -363,3 +389,20 @@ def write_png(path: str, rgb8: np.ndarray) -> None:
     a = np.ascontiguousarray(rgb8, dtype=np.uint8)
     h, w, _ = a.shape
     _check(lib.rt_write_png(os.fsencode(path), w, h, a.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+
+def write_pfm(path: str, image: np.ndarray) -> None:
+    a = np.ascontiguousarray(image, dtype=np.float32)
+    h, w, _ = a.shape
+    _check(lib.rt_write_pfm(os.fsencode(path), w, h, _fptr(a)))
+
+
+def read_pfm(path: str) -> np.ndarray:
+    """Reads a colour PFM written by write_pfm / Scene.render_frames back as (H, W, 3), row 0 on top."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"PF":
+            raise ValueError(f"{path}: not a colour PFM")
+        w, h = (int(x) for x in f.readline().split())
+        scale = float(f.readline())
+        data = np.frombuffer(f.read(), dtype="<f4" if scale < 0 else ">f4")
+    return data.reshape(h, w, 3)[::-1].astype(np.float32)

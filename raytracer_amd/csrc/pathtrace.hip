@@ -1005,6 +1005,13 @@ struct rt_scene {
     std::vector<hipEvent_t> events;   // pool, reused by every call
     std::vector<char> event_tags;     // tag of the events in use, in record order
     hipEvent_t frame_begin = nullptr, frame_end = nullptr;
+    // rt_render's device buffers (sums and output image), grown on demand
+    float* frame_sum = nullptr;
+    float* frame_out = nullptr;
+    size_t frame_pixels = 0;
+    // progress reports per finished batch
+    rt_progress_fn progress = nullptr;
+    void* progress_user = nullptr;
 };
 
 namespace {
@@ -1375,7 +1382,16 @@ extern "C" int rt_scene_free(rt_scene* s) {
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     if (s->frame_begin) (void)hipEventDestroy(s->frame_begin);
     if (s->frame_end) (void)hipEventDestroy(s->frame_end);
+    if (s->frame_sum) (void)hipFree(s->frame_sum);
+    if (s->frame_out) (void)hipFree(s->frame_out);
     delete s;
+    return RT_OK;
+}
+
+extern "C" int rt_set_progress(rt_scene* s, rt_progress_fn fn, void* user) {
+    if (!s) { rt_set_error("rt_set_progress: null scene"); return RT_ERR_INVALID; }
+    s->progress = fn;
+    s->progress_user = fn ? user : nullptr;
     return RT_OK;
 }
 
@@ -1432,6 +1448,10 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         HIP_TRY(hipGetLastError());
         batches++;
         paths += f.n_paths;
+        if (s->progress) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            s->progress(paths, (uint64_t)n_samples * n_pixels, s->progress_user);
+        }
         if (stats) { // the counters are reused by the next batch: read them now
             HIP_TRY(hipMemcpyAsync(counts.data(), s->w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), s->w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1485,25 +1505,29 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* op
     if (rc != RT_OK) return rc;
     if (!out_rgb) { rt_set_error("rt_render: null output"); return RT_ERR_INVALID; }
     const uint32_t n_pixels = cam->width * cam->height;
-    float* d_sum = nullptr;
-    float* d_out = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_sum), (size_t)n_pixels * 4 * sizeof(float)));
-    if (hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n_pixels * 3 * sizeof(float)) != hipSuccess) {
-        (void)hipFree(d_sum);
-        rt_set_error("rt_render: out of device memory");
-        return RT_ERR_NOMEM;
+    if (s->frame_pixels < n_pixels) { // the buffers stay with the scene: no allocation per frame
+        if (s->frame_sum) (void)hipFree(s->frame_sum);
+        if (s->frame_out) (void)hipFree(s->frame_out);
+        s->frame_sum = s->frame_out = nullptr;
+        s->frame_pixels = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&s->frame_sum), (size_t)n_pixels * 4 * sizeof(float)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s->frame_out), (size_t)n_pixels * 3 * sizeof(float)) != hipSuccess) {
+            if (s->frame_sum) (void)hipFree(s->frame_sum);
+            s->frame_sum = nullptr;
+            (void)hipGetLastError();
+            rt_set_error("rt_render: out of device memory");
+            return RT_ERR_NOMEM;
+        }
+        s->frame_pixels = n_pixels;
     }
-    rt_stats local;
-    rc = (hipMemsetAsync(d_sum, 0, (size_t)n_pixels * 4 * sizeof(float), nullptr) == hipSuccess) ? RT_OK : RT_ERR_DEVICE;
-    if (rc == RT_OK) rc = rt_accumulate(s, cam, opt, 0, cam->num_rays, d_sum, nullptr, stats ? stats : &local);
-    if (rc == RT_OK) rc = rt_resolve(d_sum, n_pixels, d_out, nullptr);
-    if (rc == RT_OK && hipMemcpy(out_rgb, d_out, (size_t)n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+    HIP_TRY(hipMemsetAsync(s->frame_sum, 0, (size_t)n_pixels * 4 * sizeof(float), nullptr));
+    if ((rc = rt_accumulate(s, cam, opt, 0, cam->num_rays, s->frame_sum, nullptr, stats)) != RT_OK) return rc;
+    if ((rc = rt_resolve(s->frame_sum, n_pixels, s->frame_out, nullptr)) != RT_OK) return rc;
+    if (hipMemcpy(out_rgb, s->frame_out, (size_t)n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
         rt_set_error("rt_render: device to host copy failed");
-        rc = RT_ERR_DEVICE;
+        return RT_ERR_DEVICE;
     }
-    (void)hipFree(d_sum);
-    (void)hipFree(d_out);
-    return rc;
+    return RT_OK;
 }
 
 namespace {

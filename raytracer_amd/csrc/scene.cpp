@@ -8,6 +8,10 @@
 
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -479,30 +483,187 @@ std::vector<uint8_t> quantize(const float* image, size_t count) {
     return out;
 }
 
+bool ends_with(const std::string& s, const char* suffix) {
+    const size_t n = std::strlen(suffix);
+    return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+// ".pfm" -> the unclamped float image; anything else -> the reference's 8-bit PNG
+void write_image(const std::string& path, uint32_t width, uint32_t height, const float* image) {
+    int rc;
+    if (ends_with(path, ".pfm")) {
+        rc = rt_write_pfm(path.c_str(), width, height, image);
+    } else {
+        std::vector<uint8_t> rgb = quantize(image, size_t(3) * width * height);
+        rc = rt_write_png(path.c_str(), width, height, rgb.data());
+    }
+    if (rc != RT_OK) throw std::runtime_error(rt_last_error());
+}
+
+// Host threads that encode finished frames while the device renders the next.
+class FrameWriters {
+public:
+    explicit FrameWriters(unsigned n) : limit_(2 * size_t(n ? n : 1)) {
+        for (unsigned i = 0; i < (n ? n : 1); i++) threads_.emplace_back([this] { run(); });
+    }
+    ~FrameWriters() { finish(); }
+
+    // Blocks while 2 frames per thread are already waiting, which bounds the memory held.
+    void submit(std::string path, uint32_t width, uint32_t height, std::vector<float> image) {
+        std::unique_lock<std::mutex> lock(m_);
+        room_.wait(lock, [this] { return jobs_.size() < limit_; });
+        jobs_.push_back(Job{std::move(path), width, height, std::move(image)});
+        work_.notify_one();
+    }
+
+    // Waits for every file; returns the first failure's message ("" = all written).
+    std::string finish() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            closed_ = true;
+        }
+        work_.notify_all();
+        for (std::thread& t : threads_) if (t.joinable()) t.join();
+        return error_;
+    }
+
+private:
+    struct Job {
+        std::string path;
+        uint32_t width, height;
+        std::vector<float> image;
+    };
+
+    void run() {
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                work_.wait(lock, [this] { return closed_ || !jobs_.empty(); });
+                if (jobs_.empty()) return;
+                job = std::move(jobs_.front());
+                jobs_.pop_front();
+                room_.notify_one();
+            }
+            try {
+                write_image(job.path, job.width, job.height, job.image.data());
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> lock(m_);
+                if (error_.empty()) error_ = e.what();
+            }
+        }
+    }
+
+    std::mutex m_;
+    std::condition_variable work_, room_;
+    std::deque<Job> jobs_;
+    std::vector<std::thread> threads_;
+    std::string error_;
+    size_t limit_;
+    bool closed_ = false;
+};
+
+// printf pattern with exactly one integer conversion -> file name of frame i
+std::string frame_path(const std::string& pattern, unsigned frame) {
+    int conversions = 0;
+    for (size_t i = 0; i < pattern.size(); i++) {
+        if (pattern[i] != '%') continue;
+        if (i + 1 < pattern.size() && pattern[i + 1] == '%') { i++; continue; }
+        size_t j = i + 1;
+        while (j < pattern.size() && (pattern[j] == '0' || pattern[j] == '-')) j++;
+        while (j < pattern.size() && pattern[j] >= '0' && pattern[j] <= '9') j++;
+        if (j >= pattern.size() || (pattern[j] != 'd' && pattern[j] != 'u' && pattern[j] != 'i'))
+            throw std::runtime_error("frame pattern: only %d, %u, %i (with width) are accepted");
+        conversions++;
+        i = j;
+    }
+    if (conversions != 1) throw std::runtime_error("frame pattern needs exactly one integer conversion, e.g. frame_%04d.png");
+    std::vector<char> buf(pattern.size() + 32);
+    std::snprintf(buf.data(), buf.size(), pattern.c_str(), frame);
+    return std::string(buf.data());
+}
+
+// The reference's progress line (src/raytrace.cu:601-627): a 50-column bar,
+// the percentage and the predicted remaining time.
+struct ProgressBar {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool drawn = false;
+
+    static void report(uint64_t done, uint64_t total, void* user) {
+        ProgressBar* self = static_cast<ProgressBar*>(user);
+        if (done >= total && !self->drawn) return; // single-batch frame: nothing to show
+        const double frac = total ? double(done) / double(total) : 1.0;
+        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - self->t0).count();
+        const double remaining = frac > 0 ? elapsed * (1.0 - frac) / frac : 0.0;
+        char bar[51];
+        const int filled = static_cast<int>(frac * 50);
+        for (int i = 0; i < 50; i++) bar[i] = i < filled ? '=' : (i == filled ? '>' : ' ');
+        bar[50] = 0;
+        std::printf("\r[%s] %3d %% | Remaining: %.1f s   ", bar, static_cast<int>(frac * 100), remaining);
+        if (done >= total) std::printf("\n");
+        std::fflush(stdout);
+        self->drawn = true;
+    }
+};
+
 } // namespace
 
-void Scene::render(std::string imagepath, size_t seed) {
-    rt_scene_desc desc;
-    rt_camera cam;
-    describe(&desc, &cam);
+void Scene::sync_device_scene() {
     if (device_scene_stale_ || !device_scene_) {
+        rt_scene_desc desc;
+        describe(&desc, nullptr);
         release_device_scene();
         if (rt_scene_upload(&desc, &device_scene_) != RT_OK) throw std::runtime_error(rt_last_error());
         device_scene_stale_ = false;
     }
+}
+
+void Scene::render(std::string imagepath, size_t seed) {
+    rt_camera cam;
+    describe(nullptr, &cam);
+    sync_device_scene();
     rt_options opt = options_from(settings, seed);
     image_.assign(size_t(3) * cam.width * cam.height, 0.f);
 
+    ProgressBar bar;
+    if (verbose) rt_set_progress(device_scene_, &ProgressBar::report, &bar);
     auto t0 = std::chrono::steady_clock::now();
-    if (rt_render(device_scene_, &cam, &opt, image_.data(), &stats_) != RT_OK) throw std::runtime_error(rt_last_error());
+    const int rc = rt_render(device_scene_, &cam, &opt, image_.data(), &stats_);
+    rt_set_progress(device_scene_, nullptr, nullptr);
+    if (rc != RT_OK) throw std::runtime_error(rt_last_error());
     double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (verbose) std::printf("Finished raytracing in %.3f seconds.\n", seconds);
 
-    if (!imagepath.empty()) {
-        std::vector<uint8_t> rgb = quantize(image_.data(), image_.size());
-        if (rt_write_png(imagepath.c_str(), cam.width, cam.height, rgb.data()) != RT_OK)
-            throw std::runtime_error(rt_last_error());
+    if (!imagepath.empty()) write_image(imagepath, cam.width, cam.height, image_.data());
+}
+
+double Scene::render_frames(std::string pattern, size_t first_seed, unsigned n_frames, CU_Vector3f rotate_step,
+                            CU_Vector3f move_step, unsigned first, unsigned stride, unsigned writers) {
+    if (stride == 0) throw std::runtime_error("render_frames: stride must be at least 1");
+    if (!pattern.empty()) (void)frame_path(pattern, 0); // reject a bad pattern before any work
+    sync_device_scene();
+    auto t0 = std::chrono::steady_clock::now();
+    {
+        FrameWriters pool(pattern.empty() ? 1 : writers);
+        for (unsigned i = 0; i < n_frames; i++) {
+            if (i > 0) { // the pose of frame i does not depend on which frames this process draws
+                rotate_camera(rotate_step);
+                transform_camera(move_step);
+            }
+            if (i < first || (i - first) % stride != 0) continue;
+            rt_camera cam;
+            describe(nullptr, &cam);
+            rt_options opt = options_from(settings, first_seed + i);
+            image_.assign(size_t(3) * cam.width * cam.height, 0.f);
+            if (rt_render(device_scene_, &cam, &opt, image_.data(), &stats_) != RT_OK) throw std::runtime_error(rt_last_error());
+            if (!pattern.empty()) pool.submit(frame_path(pattern, i), cam.width, cam.height, image_);
+        }
+        const std::string failure = pool.finish();
+        if (!failure.empty()) throw std::runtime_error(failure);
     }
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (verbose) std::printf("Rendered %u frames in %.3f seconds.\n", n_frames > first ? (n_frames - first + stride - 1) / stride : 0, seconds);
+    return seconds;
 }
 
 int raytrace_spheres(Sphere* spheres, size_t sphere_count, Triangle* triangles, size_t triangle_count,
@@ -634,6 +795,19 @@ extern "C" int rt_write_png(const char* path, uint32_t width, uint32_t height, c
     return RT_OK;
 }
 
+extern "C" int rt_write_pfm(const char* path, uint32_t width, uint32_t height, const float* rgb) {
+    if (!path || !rgb || width == 0 || height == 0) { rt_set_error("rt_write_pfm: bad argument"); return RT_ERR_INVALID; }
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) { rt_set_error("rt_write_pfm: cannot open %s", path); return RT_ERR_IO; }
+    // "PF" = three channels; a negative scale marks little-endian samples; rows run bottom to top
+    bool ok = std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height) > 0;
+    const size_t row = size_t(3) * width;
+    for (uint32_t y = height; ok && y-- > 0;) ok = std::fwrite(rgb + row * y, sizeof(float), row, f) == row;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { rt_set_error("rt_write_pfm: short write to %s", path); return RT_ERR_IO; }
+    return RT_OK;
+}
+
 // ------------------------------------------------- C view of class Scene
 
 struct rt_host_scene {
@@ -754,6 +928,19 @@ int rt_host_scene_render(rt_host_scene* s, const char* png_path, size_t seed) {
     // failures inside render come from the device half, which already set
     // the message; classify them as device errors
     return rc == RT_ERR_INVALID ? RT_ERR_DEVICE : rc;
+}
+
+int rt_host_scene_render_frames(rt_host_scene* s, const char* pattern, size_t first_seed, uint32_t n_frames,
+                                const float rotate_step[3], const float move_step[3], uint32_t first, uint32_t stride,
+                                uint32_t writers, double* out_seconds) {
+    if (!s || stride == 0) { rt_set_error("rt_host_scene_render_frames: null scene or zero stride"); return RT_ERR_INVALID; }
+    const Vec3f rot = rotate_step ? vec3_of(rotate_step) : Vec3f();
+    const Vec3f mov = move_step ? vec3_of(move_step) : Vec3f();
+    int rc = guarded("rt_host_scene_render_frames", [&] {
+        const double seconds = s->scene.render_frames(pattern ? pattern : "", first_seed, n_frames, rot, mov, first, stride, writers);
+        if (out_seconds) *out_seconds = seconds;
+    });
+    return rc;
 }
 
 int rt_host_scene_describe(rt_host_scene* s, rt_scene_desc* out_desc, rt_camera* out_cam) {

@@ -110,6 +110,16 @@ public:
     // writes an 8-bit RGB PNG.  The image depends only on the scene and seed.
     void render(std::string imagepath, size_t seed);
 
+    // The frame loop of the reference's README (README.md:24): frame i is drawn
+    // after i camera steps (rotate_camera(rotate_step), then
+    // transform_camera(move_step)) with seed first_seed + i and written to the
+    // file `pattern` names for i ("frame_%04d.png"; ".pfm" = float image;
+    // empty = no files).  Frames first, first + stride, ... are rendered, the
+    // camera takes every step.  Files are encoded by `writers` host threads
+    // while the next frame renders.  Returns the wall time in seconds.
+    double render_frames(std::string pattern, size_t first_seed, unsigned n_frames, CU_Vector3f rotate_step,
+                         CU_Vector3f move_step, unsigned first = 0, unsigned stride = 1, unsigned writers = 4);
+
     void set_camera_intrinsics(float fov, size_t width, size_t height);
 
     void rotate_camera(float alpha, float beta, float gamma); // degrees, R = Rz Ry Rx
@@ -144,6 +154,7 @@ public:
 private:
     int add_material(const Material& m);
     void release_device_scene();
+    void sync_device_scene(); // uploads the scene when it changed since the last upload
 
     std::vector<float> sphere_pos_, sphere_radius_;
     std::vector<int32_t> sphere_material_;

@@ -27,6 +27,17 @@ def sample_range(rank: int, world: int, spp: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def frame_share(rank: int, world: int) -> Tuple[int, int]:
+    """(first, stride) for Scene.render_frames: rank r of N draws frames r, r + N, r + 2N, ...
+
+    A frame sequence shards over whole frames (every frame has its own seed and camera pose), so
+    there is no exchange step at all: each rank writes its own files.
+    """
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError(f"bad partition request rank={rank} world={world}")
+    return rank, world
+
+
 class FrameRenderer:
     """Renders whole frames of one scene with the samples split over a process group.
 
