@@ -38,6 +38,15 @@ def frame_share(rank: int, world: int) -> Tuple[int, int]:
     return rank, world
 
 
+class _Slot:
+    """Buffers of one frame in flight."""
+
+    def __init__(self, torch, n_pixels, device):
+        self.sum = torch.zeros(n_pixels * 4, dtype=torch.float32, device=device)
+        self.image = torch.empty(n_pixels * 3, dtype=torch.float32, device=device)
+        self.done = None  # event: the frame that last used these buffers has been resolved
+
+
 class FrameRenderer:
     """Renders whole frames of one scene with the samples split over a process group.
 
@@ -47,11 +56,18 @@ class FrameRenderer:
     defaults call the HIP library on the current CUDA stream; the CPU test
     suite injects host implementations to exercise the partition + reduction
     logic under the gloo backend.
+
+    render() returns a finished-in-stream-order image.  render_async() keeps
+    `depth` frames in flight: with the "nccl" backend the all-reduce and the
+    resolve of frame i run on RCCL's stream and a side stream while the current
+    stream already accumulates frame i + 1, so a sequence of frames costs
+    max(compute, exchange) per frame instead of their sum.  Call wait() (or
+    synchronize the device) before reading images returned by render_async().
     """
 
     def __init__(self, dev, cam, opt, *, group=None, tensor_device="cuda",
                  accumulate: Optional[Callable] = None, resolve: Optional[Callable] = None,
-                 want_stats: bool = False):
+                 want_stats: bool = False, depth: int = 2, exchange_in_group_of_one: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -64,12 +80,29 @@ class FrameRenderer:
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.n_pixels = cam.width * cam.height
         self.s_begin, self.s_end = sample_range(self.rank, self.world, cam.num_rays)
-        self.sum = torch.zeros(self.n_pixels * 4, dtype=torch.float32, device=tensor_device)
-        self.image = torch.empty(self.n_pixels * 3, dtype=torch.float32, device=tensor_device)
+        if depth < 1:
+            raise ValueError("depth must be at least 1")
+        self.slots = [_Slot(torch, self.n_pixels, tensor_device) for _ in range(depth)]
+        self.frame = 0
+        on_gpu = str(tensor_device).startswith("cuda")
+        # overlap needs a collective that runs on a device stream of its own
+        self.overlap = bool(on_gpu and self.distributed and dist.get_backend(group) == "nccl")
+        self.side = torch.cuda.Stream() if self.overlap else None
+        # a group of one has nothing to exchange; rehearsals of the stream logic can ask for the collective anyway
+        self.exchange = self.world > 1 or (exchange_in_group_of_one and self.distributed)
         self.want_stats = want_stats
         self.last_stats = None
         self._accumulate = accumulate or self._hip_accumulate
         self._resolve = resolve or self._hip_resolve
+
+    # the buffers of the most recent frame (kept for callers that look at them)
+    @property
+    def sum(self):
+        return self.slots[(self.frame - 1) % len(self.slots)].sum
+
+    @property
+    def image(self):
+        return self.slots[(self.frame - 1) % len(self.slots)].image
 
     def _stream(self) -> int:
         return self.torch.cuda.current_stream().cuda_stream
@@ -83,12 +116,39 @@ class FrameRenderer:
 
         rt.resolve(sum_tensor.data_ptr(), self.n_pixels, out_tensor.data_ptr(), self._stream())
 
-    def render(self):
-        """One frame; returns the (H, W, 3) image tensor (same storage every call)."""
-        self.sum.zero_()
+    def render_async(self, cam=None, opt=None):
+        """Enqueues one frame; returns its (H, W, 3) image tensor, valid after wait()."""
+        torch = self.torch
+        cam = cam if cam is not None else self.cam
+        opt = opt if opt is not None else self.opt
+        slot = self.slots[self.frame % len(self.slots)]
+        self.frame += 1
+        if slot.done is not None:  # the frame that used these buffers `depth` frames ago
+            torch.cuda.current_stream().wait_event(slot.done)
+            slot.done = None
+        slot.sum.zero_()
         if self.s_end > self.s_begin:
-            self._accumulate(self.cam, self.opt, self.s_begin, self.s_end, self.sum)
-        if self.world > 1:
-            self.dist.all_reduce(self.sum, group=self.group)
-        self._resolve(self.sum, self.image)
-        return self.image.view(self.cam.height, self.cam.width, 3)
+            self._accumulate(cam, opt, self.s_begin, self.s_end, slot.sum)
+        if self.exchange and self.overlap:
+            # the collective is ordered after the accumulate; the current stream does not wait for it
+            work = self.dist.all_reduce(slot.sum, group=self.group, async_op=True)
+            with torch.cuda.stream(self.side):
+                work.wait()  # makes the side stream wait for the collective
+                self._resolve(slot.sum, slot.image)
+                slot.done = self.side.record_event()
+        else:
+            if self.exchange:
+                self.dist.all_reduce(slot.sum, group=self.group)
+            self._resolve(slot.sum, slot.image)
+        return slot.image.view(cam.height, cam.width, 3)
+
+    def wait(self) -> None:
+        """Orders the current stream after every frame enqueued so far."""
+        if self.overlap:
+            self.torch.cuda.current_stream().wait_stream(self.side)
+
+    def render(self, cam=None, opt=None):
+        """One frame; returns the (H, W, 3) image tensor, ordered on the current stream."""
+        image = self.render_async(cam, opt)
+        self.wait()
+        return image

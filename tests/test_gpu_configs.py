@@ -402,3 +402,51 @@ def test_two_ranks_on_the_gpu_reproduce_the_single_rank_frame(tmp_path):
     np.testing.assert_allclose(a, single, rtol=3e-6, atol=1e-4)
     ref, _ = ob.render_image(desc, cam, ob.options(seed=31))
     np.testing.assert_allclose(a, ref, rtol=3e-6, atol=1e-4)
+
+
+def _pipelined_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from raytracer_amd.distributed import FrameRenderer
+
+        rt.init(0)
+        s = load("mesh_scene", 160, 120, 5)
+        desc, cam = s.describe()
+        dev = s.upload()
+        r = FrameRenderer(dev, cam, rt.make_options(seed=40), exchange_in_group_of_one=True)
+        assert r.overlap and r.exchange
+        # seven frames with their own seeds through two slots, nothing waited for in between
+        images = [r.render_async(opt=rt.make_options(seed=40 + i)) for i in range(7)]
+        last_two = [images[5].clone(), images[6].clone()]  # clone is ordered on the current stream: too early on purpose
+        r.wait()
+        got = [images[5].cpu().numpy().copy(), images[6].cpu().numpy().copy()]
+        for i, g in zip((5, 6), got):
+            want, _ = dev.render(cam, rt.make_options(seed=40 + i))
+            assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), f"frame {i}"
+        # the synchronous call returns a finished frame
+        img = r.render(opt=rt.make_options(seed=99)).cpu().numpy()
+        want, _ = dev.render(cam, rt.make_options(seed=99))
+        assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+        del last_two
+        np.save(os.path.join(out_dir, "ok.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_frames_over_rccl_group_of_one(tmp_path):
+    """Stream logic of the overlapped path (RCCL collective on its own stream, resolve on a side
+    stream, buffer reuse after two frames), rehearsed on the one GPU of the test box."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    mp.start_processes(_pipelined_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    assert os.path.exists(tmp_path / "ok.npy")

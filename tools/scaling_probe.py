@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Rehearses the per-rank load of an N-GPU run on ONE GPU.
+
+For N in 1, 2, 4, 8 the process renders the share of samples rank 0 of N would
+get (spp / N per pixel), runs the all-reduce on a one-rank RCCL group (so the
+collective's launch path and the stream overlap are exercised; the transfer
+itself is missing) and reports ms per frame.  ms(1) / ms(N) is an upper bound
+of the strong-scaling factor bench.py --gpus N can reach.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import raytracer_amd as rt
+    from raytracer_amd.distributed import FrameRenderer, sample_range
+
+    rt.init(0)
+    scene = rt.Scene()
+    scene.load_scene(os.path.join(rt.ASSETS, "scenes", "mesh_scene.json"))
+    desc, cam = scene.describe()
+    dev = scene.upload()
+    opt = rt.make_options(seed=1)
+    out = {}
+    for n in (1, 2, 4, 8):
+        for overlapped in (True, False):
+            r = FrameRenderer(dev, cam, opt, exchange_in_group_of_one=True)
+            r.s_begin, r.s_end = sample_range(0, n, cam.num_rays)
+            step = r.render_async if overlapped else r.render
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            frames = 40
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / frames * 1e3
+            out[f"share_1_of_{n}_{'overlapped' if overlapped else 'serial'}_ms"] = ms
+            print(f"share 1/{n} ({r.s_end - r.s_begin} spp) {'overlapped' if overlapped else 'serial    '}: {ms:.3f} ms/frame", flush=True)
+    print(json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
