@@ -158,27 +158,98 @@ __device__ __forceinline__ V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
 
 // ---------------------------------------------------------- intersection
 
-// Nearest sphere along a ray (reference get_distance, src/raytrace.cu:53-87).
-__device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, V3 ray, V3 start, int& id) {
-    float min_dist = INFINITY;
-    for (uint32_t i = 0; i < sc.n_spheres; i++) {
-        const float4 s = sc.sphere[i];
-        const V3 oc = start - xyz(s);
-        const float b = dot(ray, oc);
-        const float ocn = norm(oc);
-        const float R = s.w;
-        const float delta = b * b - ocn * ocn + R * R;
-        if (delta >= 0) {
-            const float sq = sqrtf(delta);
-            const float t2 = -b + sq;
-            if (t2 >= 0) {
-                const float t1 = -b - sq;
-                const float t = t1 >= 0 ? t1 : t2;
-                if (id < 0 || t < min_dist) { min_dist = t; id = (int)i; }
-            }
+// The first kSphereCache spheres of the scene, staged in LDS by the kernels
+// that test every sphere for every path: the index is wave-uniform, so an LDS
+// read is a broadcast, whereas a global load (which the compiler cannot turn
+// into a scalar load in kernels that also write global memory) stalls every
+// iteration on the vector memory path.
+constexpr uint32_t kSphereCache = 64;
+
+struct Spheres {
+    const float4* lds;
+    const float4* global;
+    uint32_t cached, n;
+    __device__ __forceinline__ float4 operator[](uint32_t i) const { return i < cached ? lds[i] : global[i]; }
+};
+
+// All threads of the workgroup must call it.
+__device__ __forceinline__ Spheres stage_spheres(const DeviceScene& sc, float4* lds) {
+    Spheres s;
+    s.lds = lds;
+    s.global = sc.sphere;
+    s.n = sc.n_spheres;
+    s.cached = s.n < kSphereCache ? s.n : kSphereCache;
+    for (uint32_t i = threadIdx.x; i < s.cached; i += kBlock) lds[i] = sc.sphere[i];
+    __syncthreads();
+    return s;
+}
+
+// One sphere of the reference's scan (get_distance, src/raytrace.cu:59-84)
+// given b = u . OC and n2 = |OC| * |OC|.
+__device__ __forceinline__ void sphere_step(float b, float n2, float R, uint32_t i, float& min_dist, int& id) {
+    const float delta = b * b - n2 + R * R;
+    if (delta >= 0) {
+        const float sq = sqrtf(delta);
+        const float t2 = -b + sq;
+        if (t2 >= 0) {
+            const float t1 = -b - sq;
+            const float t = t1 >= 0 ? t1 : t2;
+            if (id < 0 || t < min_dist) { min_dist = t; id = (int)i; }
         }
     }
+}
+
+// Nearest sphere along a ray (reference get_distance, src/raytrace.cu:53-87).
+__device__ __forceinline__ float nearest_sphere(const Spheres& sp, V3 ray, V3 start, int& id) {
+    float min_dist = INFINITY;
+    for (uint32_t i = 0; i < sp.n; i++) {
+        const float4 s = sp[i];
+        const V3 oc = start - xyz(s);
+        const float ocn = norm(oc);
+        sphere_step(dot(ray, oc), ocn * ocn, s.w, i, min_dist, id);
+    }
     return min_dist;
+}
+
+// The same scan for two rays that leave the same point (a shadow ray and the
+// bounce ray of one hit): OC and its norm depend on the start only and are
+// computed once per sphere.  A ray whose flag is false keeps (inf, id).
+__device__ __forceinline__ void nearest_sphere_pair(const Spheres& sp, V3 start, bool do_a, V3 ray_a, float& dist_a, int& id_a,
+                                                    bool do_b, V3 ray_b, float& dist_b, int& id_b) {
+    dist_a = INFINITY;
+    dist_b = INFINITY;
+    for (uint32_t i = 0; i < sp.n; i++) {
+        const float4 s = sp[i];
+        const V3 oc = start - xyz(s);
+        const float ocn = norm(oc);
+        const float n2 = ocn * ocn;
+        if (do_a) sphere_step(dot(ray_a, oc), n2, s.w, i, dist_a, id_a);
+        if (do_b) sphere_step(dot(ray_b, oc), n2, s.w, i, dist_b, id_b);
+    }
+}
+
+// One box of the scan below for a ray, given lo = box_min - start, hi = box_max - start.
+__device__ __forceinline__ bool box_hit(V3 lo, V3 hi, V3 ray) {
+    const V3 axis[3] = {mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1)};
+    float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float rdn = dot_z(ray, axis[i]);
+        if (rdn != 0) {
+            const float a = dot_z(lo, axis[i]) / rdn;
+            const float b = dot_z(hi, axis[i]) / rdn;
+            if (a < b) { t0[i] = a; t1[i] = b; }
+            else       { t0[i] = b; t1[i] = a; }
+        }
+    }
+    // running min / max seeded with element 0 (reference include/vector.cuh:69-85)
+    float mn = t1[0];
+    if (t1[1] < mn) mn = t1[1];
+    if (t1[2] < mn) mn = t1[2];
+    float mx = t0[0];
+    if (t0[1] > mx) mx = t0[1];
+    if (t0[2] > mx) mx = t0[2];
+    return mn > mx;
 }
 
 // Slab test against every box until one is hit (reference
@@ -186,30 +257,8 @@ __device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, V3 ray, V
 // the ray is parallel to the slab, there is no t > 0 requirement, and the
 // verdict is min(exit) > max(entry).
 __device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, V3 ray, V3 start) {
-    const V3 axis[3] = {mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1)};
-    for (uint32_t o = 0; o < sc.n_boxes; o++) {
-        const V3 lo = xyz(sc.box_min[o]) - start;
-        const V3 hi = xyz(sc.box_max[o]) - start;
-        float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const float rdn = dot_z(ray, axis[i]);
-            if (rdn != 0) {
-                const float a = dot_z(lo, axis[i]) / rdn;
-                const float b = dot_z(hi, axis[i]) / rdn;
-                if (a < b) { t0[i] = a; t1[i] = b; }
-                else       { t0[i] = b; t1[i] = a; }
-            }
-        }
-        // running min / max seeded with element 0 (reference include/vector.cuh:69-85)
-        float mn = t1[0];
-        if (t1[1] < mn) mn = t1[1];
-        if (t1[2] < mn) mn = t1[2];
-        float mx = t0[0];
-        if (t0[1] > mx) mx = t0[1];
-        if (t0[2] > mx) mx = t0[2];
-        if (mn > mx) return true;
-    }
+    for (uint32_t o = 0; o < sc.n_boxes; o++)
+        if (box_hit(xyz(sc.box_min[o]) - start, xyz(sc.box_max[o]) - start, ray)) return true;
     return false;
 }
 
@@ -240,6 +289,21 @@ __device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, int use_boxes,
     if (sc.n_triangles == 0) return false;
     if (!use_boxes) return true;
     return any_box_hit(sc, ray, start);
+}
+
+// needs_mesh for two rays that leave the same point; box - start is shared.
+__device__ __forceinline__ void needs_mesh_pair(const DeviceScene& sc, int use_boxes, V3 start, bool do_a, V3 ray_a, bool& walk_a,
+                                                bool do_b, V3 ray_b, bool& walk_b) {
+    walk_a = false;
+    walk_b = false;
+    if (sc.n_triangles == 0) return;
+    if (!use_boxes) { walk_a = do_a; walk_b = do_b; return; }
+    for (uint32_t o = 0; o < sc.n_boxes; o++) {
+        const V3 lo = xyz(sc.box_min[o]) - start;
+        const V3 hi = xyz(sc.box_max[o]) - start;
+        if (do_a && !walk_a) walk_a = box_hit(lo, hi, ray_a);
+        if (do_b && !walk_b) walk_b = box_hit(lo, hi, ray_b);
+    }
 }
 
 // Barycentrics of a known hit, by the expressions of the reference's triangle
@@ -635,25 +699,36 @@ struct Frame {
 __device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return p % f.n_pixels; }
 __device__ __forceinline__ uint32_t path_sample(const Frame& f, uint32_t p) { return f.sample_begin + p / f.n_pixels; }
 
-// Nearest sphere + box test for a freshly generated ray, state write-back,
-// queueing for k_mesh.  All lanes of the wavefront must call it.
-__device__ __forceinline__ void launch_ray(const DeviceScene& sc, const Work& w, const Frame& f, uint32_t counter,
+// State write-back of a freshly generated ray whose nearest sphere (ts, sid)
+// and mesh verdict are known, and queueing for k_mesh.  All lanes of the
+// wavefront must call it.
+__device__ __forceinline__ void commit_ray(const Work& w, uint32_t counter, bool alive, uint32_t p, V3 start, V3 ray,
+                                           float ts, int sid, bool walk) {
+    if (alive) {
+        w.ray_o[p] = make_float4(start.x, start.y, start.z, ts);
+        w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
+        w.hit[p] = kNoHit;
+    }
+    enqueue(w, counter, alive && walk, start, ray, p, ts);
+}
+
+// Nearest sphere + box test for a freshly generated ray, then commit_ray.
+__device__ __forceinline__ void launch_ray(const DeviceScene& sc, const Spheres& sp, const Work& w, const Frame& f, uint32_t counter,
                                            bool alive, uint32_t p, V3 start, V3 ray) {
     int sid = -1;
     float ts = INFINITY;
     bool walk = false;
     if (alive) {
-        ts = nearest_sphere(sc, ray, start, sid);
+        ts = nearest_sphere(sp, ray, start, sid);
         walk = needs_mesh(sc, f.bounding_box, ray, start);
-        w.ray_o[p] = make_float4(start.x, start.y, start.z, ts);
-        w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
-        w.hit[p] = kNoHit;
     }
-    enqueue(w, counter, walk, start, ray, p, ts);
+    commit_ray(w, counter, alive, p, start, ray, ts, sid, walk);
 }
 
 // Camera sample of every path of the batch (reference src/raytrace.cu:479-494).
 __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f) {
+    __shared__ float4 sphere_lds[kSphereCache];
+    const Spheres sp = stage_spheres(sc, sphere_lds);
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     const bool alive = p < f.n_paths;
     V3 start = mk(f.pos[0], f.pos[1], f.pos[2]);
@@ -700,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
         w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
         w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
     }
-    launch_ray(sc, w, f, 0, alive, p, start, ray);
+    launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
 }
 
 // Adds the light contributions a path left pending at its previous hit, in
@@ -750,16 +825,30 @@ __device__ __forceinline__ V3 reflect(V3 ray, V3 N) { return ray - (2 * dot(ray,
 // One bounce of every live path (reference get_color loop body,
 // src/raytrace.cu:317-442).  `depth` is the bounce index; counter depth+1
 // receives the rays this bounce queues for k_mesh.
+//
+// The kernel has two parts.  The first, divergent by material, finds the hit
+// point, its normal and the bounce ray.  The second is shared by all lanes:
+// the sphere scans and box tests of the shadow rays (diffuse hits) and of the
+// bounce ray.  The first light's shadow ray and the bounce ray of a diffuse
+// hit leave the same point, so their scans run as one (nearest_sphere_pair).
 __global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
+    __shared__ float4 sphere_lds[kSphereCache];
+    const Spheres sp = stage_spheres(sc, sphere_lds);
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t counter = (uint32_t)depth + 1u;
-    bool alive = false;
+    bool alive = false; // the path continues with a bounce ray
+    bool lit = false;   // diffuse hit: the lights are evaluated at `start`
+    bool open = false;  // the path was alive on entry: its radiance record is rewritten
     V3 start = mk(0, 0, 0), ray = mk(0, 0, 1);
+    V3 P = mk(0, 0, 0), N = mk(0, 0, 1), L = mk(0, 0, 0);
+    V3 weight = mk(0, 0, 0), colour = mk(0, 0, 0); // path weight before this hit, surface colour
+    uint32_t flags = 0;
     if (p < f.n_paths) {
-        float4 rad = w.rad[p];
-        uint32_t flags = __float_as_uint(rad.w);
+        const float4 rad = w.rad[p];
+        flags = __float_as_uint(rad.w);
         if (flags & F_ALIVE) {
-            V3 L = mk(rad.x, rad.y, rad.z);
+            open = true;
+            L = mk(rad.x, rad.y, rad.z);
             if (flags & F_PENDING) {
                 L = settle_pending(sc, w, f.n_paths, p, L);
                 flags &= ~F_PENDING;
@@ -781,12 +870,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame 
             if (tt < min_dist) { min_dist = tt; sid = -1; tid = tmp; }
 
             if (sid >= 0 || tid >= 0) {
-                const V3 P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : start + min_dist * ray;
-                V3 N;
+                P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : start + min_dist * ray;
                 int m;
                 if (sid >= 0) {
                     m = sc.sphere_mat[sid];
-                    N = normalize(P - xyz(sc.sphere[sid]));
+                    N = normalize(P - xyz(sp[(uint32_t)sid]));
                 } else {
                     float alpha, beta, gamma;
                     barycentrics(sc, tid, ray, start, alpha, beta, gamma);
@@ -796,9 +884,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame 
                 }
                 const float4 mc = sc.mat_color[m];
                 const int type = __float_as_int(mc.w);
-                const V3 colour = xyz(mc);
-                float4 th = w.thr[p];
-                V3 albedo = xyz(th);
+                colour = xyz(mc);
+                const float4 th = w.thr[p];
+                weight = xyz(th);
+                V3 next_weight = weight;
                 uint32_t dim = __float_as_uint(th.w);
                 const rt_rng_key rng = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
                 alive = true;
@@ -806,47 +895,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame 
                 if (type == RT_DIFFUSE) {
                     if (!f.indirect && depth == 0) flags |= F_EARLY;
                     if (f.antialiasing) flags &= ~F_EARLY;
-                    const V3 lifted = P + scale_d(0.01, N);
-                    bool deferred = false;
-                    for (uint32_t l = 0; l < sc.n_lights; l++) {
-                        const float4 li = sc.light[l];
-                        const V3 lp = xyz(li);
-                        const V3 sp = lp - P;
-                        const float d = norm(sp);
-                        const V3 wi = (1.f / d) * sp;
-                        const float nwi = fmaxf(dot(N, wi), 0.f);
-                        // shadow ray (reference is_visible, src/raytrace.cu:218-244)
-                        const V3 sray = normalize(lp - lifted);
-                        int shadow_sid = -1;
-                        const float ds = nearest_sphere(sc, sray, lifted, shadow_sid);
-                        const float dist = norm(lp - lifted);
-                        const bool blocked = ds < dist;
-                        const bool walk = !blocked && needs_mesh(sc, f.bounding_box, sray, lifted);
-                        // ((I / (4 pi^2 d^2) * colour) * visible) * N.wi, the
-                        // first factor in double (reference src/raytrace.cu:360)
-                        const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
-                        const V3 direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
-                        const V3 c = albedo * direct;
-                        const size_t slot = (size_t)p * sc.n_lights + l;
-                        if (walk) {
-                            if (!deferred) // first pending light: clear the earlier slots
-                                for (uint32_t e = 0; e < l; e++) w.pend[(size_t)p * sc.n_lights + e].w = PEND_NONE;
-                            deferred = true;
-                            w.pend[slot] = make_float4(c.x, c.y, c.z, dist);
-                            w.hit[(size_t)f.n_paths + slot] = kNoHit;
-                        } else if (deferred) {
-                            w.pend[slot] = make_float4(c.x, c.y, c.z, PEND_ALWAYS);
-                        } else {
-                            L = L + c;
-                        }
-                        enqueue(w, counter, walk, lifted, sray, (uint32_t)(f.n_paths + slot), dist);
-                    }
-                    if (deferred) flags |= F_PENDING;
+                    lit = true;
+                    start = P + scale_d(0.01, N);
                     if (!f.indirect) {
                         alive = false;
                     } else {
-                        albedo = albedo * colour;
-                        start = lifted;
+                        next_weight = weight * colour;
                         const float r1 = rt_rng_uniform(rng, dim);
                         const float r2 = rt_rng_uniform(rng, dim + 1);
                         dim += 2;
@@ -892,15 +946,72 @@ __global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame 
                     }
                 }
                 if (depth + 1 >= f.max_depth) alive = false;
-                w.thr[p] = make_float4(albedo.x, albedo.y, albedo.z, __uint_as_float(dim));
+                w.thr[p] = make_float4(next_weight.x, next_weight.y, next_weight.z, __uint_as_float(dim));
             }
-            if (!alive) flags &= ~F_ALIVE;
-            w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
         }
     }
-    // NOTE: the per-light enqueue above runs inside divergent control flow;
-    // enqueue() is safe there because __ballot only counts active lanes.
-    launch_ray(sc, w, f, counter, alive, p, start, ray);
+
+    // ---- shared part: shadow rays of diffuse hits, then the bounce ray ----
+    float ts = INFINITY;
+    int sid = -1;
+    bool walk = false;
+    bool bounce_probed = false;
+    bool deferred = false;
+    for (uint32_t l = 0; l < sc.n_lights; l++) {
+        // Direct light (reference src/raytrace.cu:351-360) and its shadow ray
+        // (is_visible, src/raytrace.cu:218-244).  Lanes without a diffuse hit
+        // carry placeholders and are masked by `lit`.
+        const float4 li = sc.light[l];
+        const V3 lp = xyz(li);
+        const V3 sp_ = lp - P;
+        const float d = norm(sp_);
+        const V3 wi = (1.f / d) * sp_;
+        const float nwi = fmaxf(dot(N, wi), 0.f);
+        const V3 sray = normalize(lp - start);
+        const float dist = norm(lp - start);
+        float ds = INFINITY;
+        int shadow_sid = -1;
+        bool shadow_walk = false;
+        if (l == 0) {
+            nearest_sphere_pair(sp, start, lit, sray, ds, shadow_sid, alive, ray, ts, sid);
+            needs_mesh_pair(sc, f.bounding_box, start, lit && !(ds < dist), sray, shadow_walk, alive, ray, walk);
+            bounce_probed = true;
+        } else if (lit) {
+            ds = nearest_sphere(sp, sray, start, shadow_sid);
+            shadow_walk = !(ds < dist) && needs_mesh(sc, f.bounding_box, sray, start);
+        }
+        const size_t slot = (size_t)p * sc.n_lights + l;
+        if (lit) {
+            const bool blocked = ds < dist;
+            // ((I / (4 pi^2 d^2) * colour) * visible) * N.wi, the first
+            // factor in double (reference src/raytrace.cu:360)
+            const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
+            const V3 direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
+            const V3 c = weight * direct;
+            if (shadow_walk) {
+                if (!deferred) // first pending light: clear the earlier slots
+                    for (uint32_t e = 0; e < l; e++) w.pend[(size_t)p * sc.n_lights + e].w = PEND_NONE;
+                deferred = true;
+                w.pend[slot] = make_float4(c.x, c.y, c.z, dist);
+                w.hit[(size_t)f.n_paths + slot] = kNoHit;
+            } else if (deferred) {
+                w.pend[slot] = make_float4(c.x, c.y, c.z, PEND_ALWAYS);
+            } else {
+                L = L + c;
+            }
+        }
+        enqueue(w, counter, lit && shadow_walk, start, sray, (uint32_t)(f.n_paths + slot), dist);
+    }
+    if (deferred) flags |= F_PENDING;
+    if (open) {
+        if (!alive) flags &= ~F_ALIVE;
+        w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
+    }
+    if (!bounce_probed && alive) { // a scene without lights
+        ts = nearest_sphere(sp, ray, start, sid);
+        walk = needs_mesh(sc, f.bounding_box, ray, start);
+    }
+    commit_ray(w, counter, alive, p, start, ray, ts, sid, walk);
 }
 
 // Per pixel: add the batch's sample colours to the running sum in sample
@@ -942,6 +1053,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ s
 // rays -> state + queue, through the same launch_ray the renderer uses
 __global__ __launch_bounds__(kBlock) void k_probe_rays(DeviceScene sc, Work w, Frame f, const float* __restrict__ origins,
                                                        const float* __restrict__ dirs, int as_segments) {
+    __shared__ float4 sphere_lds[kSphereCache];
+    const Spheres sp = stage_spheres(sc, sphere_lds);
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     const bool alive = p < f.n_paths;
     V3 start = mk(0, 0, 0), ray = mk(0, 0, 1);
@@ -954,7 +1067,7 @@ __global__ __launch_bounds__(kBlock) void k_probe_rays(DeviceScene sc, Work w, F
             w.thr[p] = make_float4(norm(target - start), 0.f, 0.f, 0.f);
         }
     }
-    launch_ray(sc, w, f, 0, alive, p, start, ray);
+    launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
 }
 
 __global__ __launch_bounds__(kBlock) void k_probe_results(DeviceScene sc, Work w, Frame f, int as_segments, float* __restrict__ out_t,
