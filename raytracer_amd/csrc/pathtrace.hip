@@ -322,39 +322,62 @@ __device__ __forceinline__ void barycentrics(const DeviceScene& sc, int tri, V3 
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// Exact tail of one ray-triangle test (reference src/raytrace.cu:161-174),
-// entered only by lanes the division-free test could not reject.  The running
-// minimum starts at the ray's cut-off distance (nearest sphere hit for a
-// bounce ray, light distance for a shadow ray): a triangle at or beyond it
-// cannot change the outcome, because spheres win ties (src/raytrace.cu:203-212)
-// and a shadow ray asks for t < distance (:240).  Among equal distances the
+// Nearest hit of a lane so far.  `t` is the ray's cut-off distance while
+// index < 0 (nearest sphere hit for a bounce ray, light distance for a shadow
+// ray: a triangle at or beyond it cannot change the outcome, because spheres
+// win ties, src/raytrace.cu:203-212, and a shadow ray asks for t < distance,
+// :240).  Once a triangle is held, `t` is its distance to within a few 1e-7
+// (relative) and the exact value is the IEEE quotient num / den, which
+// hit_distance() evaluates once, after the scan.
+struct Nearest {
+    float t, num, den;
+    int index;
+};
+
+__device__ __forceinline__ Nearest nearest_init(float cutoff) { Nearest n; n.t = cutoff; n.num = 0.f; n.den = 1.f; n.index = -1; return n; }
+__device__ __forceinline__ float hit_distance(const Nearest& n) { return n.num / n.den; }
+
+// Exact comparison (reference src/raytrace.cu:164-174): t = (A-O).N / u.N must
+// be positive and nearer than the nearest so far; among equal distances the
 // lower triangle index wins, as in the reference's in-order scan.
-__device__ __forceinline__ void exact_hit(float nb, float ng, float d, float ao_dot_n, uint32_t index, float& best, int& best_i) {
+__device__ __forceinline__ void take_if_nearer_exact(float ao_dot_n, float d, uint32_t index, Nearest& best) {
+    const float t = ao_dot_n / d;
+    const float held = best.index >= 0 ? hit_distance(best) : best.t;
+    if (t > 0 && (t < held || (t == held && best.index >= 0 && (int)index < best.index))) {
+        best.t = t; best.num = ao_dot_n; best.den = d; best.index = (int)index;
+    }
+}
+
+// Exact tail of one ray-triangle test (reference src/raytrace.cu:161-174),
+// entered only by lanes the division-free test could neither reject nor
+// accept.
+__device__ __forceinline__ void exact_hit(float nb, float ng, float d, float ao_dot_n, uint32_t index, Nearest& best) {
     const float beta = nb / d;
     const float gamma = -ng / d;
     const float alpha = 1.f - beta - gamma;
-    if (alpha >= 0 && beta >= 0 && gamma >= 0) {
-        const float t = ao_dot_n / d;
-        if (t > 0 && (t < best || (t == best && best_i >= 0 && (int)index < best_i))) { best = t; best_i = (int)index; }
-    }
+    if (alpha >= 0 && beta >= 0 && gamma >= 0) take_if_nearer_exact(ao_dot_n, d, index, best);
 }
 
 // A lane the division-free test could not reject.  `lo` is the smallest of the
 // approximate alpha, beta, gamma (each within 1e-6 of the exact value when the
 // point is inside).  lo >= 1e-5 means the reference's exact values are all
-// positive, so the hit is accepted without computing them, and only its
-// distance needs the IEEE division -- and not even that when the approximate
-// distance (relative error < 4e-7) is negative or clearly beyond the best so
-// far.  Anything closer to an edge, and any NaN, takes exact_hit.
-__device__ __forceinline__ void candidate(float lo, float nb, float ng, float d, float rcp, float ao_dot_n, uint32_t index,
-                                          float& best, int& best_i) {
+// positive, so the hit is accepted without computing them.  Its approximate
+// distance t_ = (A-O).N * rcp(u.N) is within 3e-7 (relative) of the exact
+// quotient, as is the held one, so a factor 1 + 2e-6 between them decides the
+// order without a division; a negative t_ has a non-positive exact quotient.
+// Near-ties, values too small for the error bound and NaNs are decided
+// exactly.  Anything closer to an edge takes exact_hit.
+__device__ __forceinline__ void candidate(float lo, float nb, float ng, float d, float rcp, float ao_dot_n, uint32_t index, Nearest& best) {
     if (lo >= 1e-5f) {
         const float t_ = ao_dot_n * rcp;
-        if (t_ > best * 1.000002f || t_ < 0.f) return;
-        const float t = ao_dot_n / d;
-        if (t > 0 && (t < best || (t == best && best_i >= 0 && (int)index < best_i))) { best = t; best_i = (int)index; }
+        if (t_ > best.t * 1.000002f || t_ < 0.f) return;
+        if (t_ * 1.000002f < best.t && t_ > 1e-30f) {
+            best.t = t_; best.num = ao_dot_n; best.den = d; best.index = (int)index;
+        } else {
+            take_if_nearer_exact(ao_dot_n, d, index, best);
+        }
     } else {
-        exact_hit(nb, ng, d, ao_dot_n, index, best, best_i);
+        exact_hit(nb, ng, d, ao_dot_n, index, best);
     }
 }
 
@@ -378,7 +401,7 @@ __device__ __forceinline__ PairData load_pair(const f2* __restrict__ tri2, uint3
 // accepts has alpha, beta, gamma in [0, 1], where the approximations are off
 // by < 1e-6, so the 1e-5 margin never drops one; a NaN passes.
 __device__ __forceinline__ void test_pair(const PairData& p, const uint32_t* __restrict__ orig, float ox, float oy, float oz,
-                                          float ux, float uy, float uz, float& best, int& best_i) {
+                                          float ux, float uy, float uz, Nearest& best) {
     const f2 Ax = p.v[0], Ay = p.v[1], Az = p.v[2];
     const f2 e1x = p.v[3], e1y = p.v[4], e1z = p.v[5];
     const f2 e2x = p.v[6], e2y = p.v[7], e2z = p.v[8];
@@ -398,10 +421,14 @@ __device__ __forceinline__ void test_pair(const PairData& p, const uint32_t* __r
     const f2 a_ = (1.f - b_) - g_;
     const float lo0 = fminf(fminf(a_.x, b_.x), g_.x);
     const float lo1 = fminf(fminf(a_.y, b_.y), g_.y);
-    if (!(lo0 < -1e-5f) || !(lo1 < -1e-5f)) {
+    const bool c0 = !(lo0 < -1e-5f), c1 = !(lo1 < -1e-5f);
+    if (c0 || c1) {
+        // one divergent region for both triangles: a lane brings the first of its candidates
+        // (lower position first, as in the scan), the rare second one follows
         const f2 aon = (aox * Nx + aoy * Ny) + aoz * Nz;
-        if (!(lo0 < -1e-5f)) candidate(lo0, nb.x, ng.x, d.x, rcp.x, aon.x, orig[0], best, best_i);
-        if (!(lo1 < -1e-5f)) candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, orig[1], best, best_i);
+        if (c0) candidate(lo0, nb.x, ng.x, d.x, rcp.x, aon.x, orig[0], best);
+        else    candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, orig[1], best);
+        if (c0 && c1) candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, orig[1], best);
     }
 }
 
@@ -446,17 +473,17 @@ __device__ __forceinline__ uint32_t ray_position(const ShardMap& m, uint32_t ray
 // their tests skipped.
 __device__ __forceinline__ void scan_pairs(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t first,
                                            uint32_t last, float ox, float oy, float oz, float ux, float uy, float uz,
-                                           float& best, int& best_i) {
+                                           Nearest& best) {
     PairData cur = load_pair(tri2, first);
     for (uint32_t j = first; j < last; j += 2) {
         __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): `cur` has landed
         const PairData nxt = load_pair(tri2, min(j + 1, last - 1));
         __builtin_amdgcn_sched_barrier(0); // keep the request ahead of the test it overlaps
-        test_pair(cur, tri_orig + 2 * (size_t)j, ox, oy, oz, ux, uy, uz, best, best_i);
+        test_pair(cur, tri_orig + 2 * (size_t)j, ox, oy, oz, ux, uy, uz, best);
         __builtin_amdgcn_s_waitcnt(0xC07F); // `nxt` has landed
         cur = load_pair(tri2, min(j + 2, last - 1));
         __builtin_amdgcn_sched_barrier(0);
-        if (j + 1 < last) test_pair(nxt, tri_orig + 2 * (size_t)j + 2, ox, oy, oz, ux, uy, uz, best, best_i);
+        if (j + 1 < last) test_pair(nxt, tri_orig + 2 * (size_t)j + 2, ox, oy, oz, ux, uy, uz, best);
     }
 }
 
@@ -491,12 +518,11 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
         const uint32_t at = ray_position(map, ray_block, shard_capacity, active);
         const float4 o4 = q_o[at];
         const float4 d4 = q_d[at];
-        float best = d4.w; // cut-off distance
-        int best_i = -1;
+        Nearest best = nearest_init(d4.w);
         const uint32_t first = chunk * kChunkPairs;
-        scan_pairs(tri2, tri_orig, first, min(first + kChunkPairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best, best_i);
-        if (active && best_i >= 0) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)best_i;
+        scan_pairs(tri2, tri_orig, first, min(first + kChunkPairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
+        if (active && best.index >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | (uint32_t)best.index;
             atomicMin(&hit[__float_as_uint(o4.w)], key);
         }
     }
@@ -607,7 +633,8 @@ __global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ cl_pair
             const float in1 = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
             const float out1 = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
             const bool t0 = active && out0 >= fmaxf(in0, 0.f) && in0 <= d4.w;
-            const bool t1 = active && out1 >= fmaxf(in1, 0.f) && in1 <= d4.w;
+            // an odd cluster count leaves the second half of the last entry without a cluster
+            const bool t1 = active && 2 * k + 1 < n_clusters && out1 >= fmaxf(in1, 0.f) && in1 <= d4.w;
             const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1);
             if (lane == 0) {
                 if (m0) atomicAdd(&slot[2 * k], (uint32_t)__popcll(m0));
@@ -672,12 +699,11 @@ __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__
         const uint32_t at = cl_list[(size_t)c * list_capacity + (active ? e : count - 1)];
         const float4 o4 = q_o[at];
         const float4 d4 = q_d[at];
-        float best = d4.w;
-        int best_i = -1;
+        Nearest best = nearest_init(d4.w);
         const uint32_t first = c * cluster_pairs;
-        scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best, best_i);
-        if (active && best_i >= 0) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)best_i;
+        scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
+        if (active && best.index >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | (uint32_t)best.index;
             atomicMin(&hit[__float_as_uint(o4.w)], key);
         }
     }
@@ -1447,8 +1473,8 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
         cl_min[c] = make_float4(lo[0] - pad, lo[1] - pad, lo[2] - pad, 0.f);
         cl_max[c] = make_float4(hi[0] + pad, hi[1] + pad, hi[2] + pad, 0.f);
     }
-    // the same bounds, two clusters per entry for k_bin64; an odd count is
-    // padded with an inverted box no ray can touch
+    // the same bounds, two clusters per entry for k_bin64; the unused half of
+    // the last entry of an odd count is never read as a cluster (k_bin64 skips it)
     std::vector<float2> cl_pair(6 * (((size_t)n_clusters + 1) / 2), make_float2(1e30f, 1e30f));
     for (uint32_t c = 0; c < ((n_clusters + 1) / 2) * 2; c++) {
         const bool real = c < n_clusters;

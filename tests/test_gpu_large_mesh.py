@@ -1,0 +1,61 @@
+"""Meshes larger than the shipped cat model: more than 64 culling clusters (the general binning
+kernel) and more than 65 536 triangles (clusters grow beyond 64 triangles)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import raytracer_amd as rt
+from helpers import SCENES, same_bits
+
+sys.path.insert(0, os.path.join(rt.REPO_ROOT, "tools"))
+import make_mesh  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def scene_with_mesh(tmp_path, n_lat, n_lon, material, width, height, spp):
+    v, n, t = make_mesh.bumpy_sphere(n_lat, n_lon)
+    path = tmp_path / f"bumpy_{n_lat}x{n_lon}.obj"
+    make_mesh.write_obj(str(path), v, n, t)
+    s = rt.Scene()
+    s.load_scene(os.path.join(SCENES, "simple.json"))
+    s.set_camera_intrinsics(60.0, width, height)
+    s.set_num_rays(spp)
+    s.add_object(str(path), [0, 2, 8], [1, 1, 1], [10, 25, 0], [0.9, 0.6, 0.3], material, 1.0, 1.5)
+    return s, len(t)
+
+
+@pytest.mark.parametrize("n_lat,n_lon,material", [(32, 62, rt.DIFFUSE), (100, 200, rt.DIFFUSE), (60, 90, rt.GLASS), (200, 400, rt.MIRROR)])
+def test_large_mesh_culled_equals_exhaustive_equals_oracle(tmp_path, n_lat, n_lon, material):
+    s, n_tri = scene_with_mesh(tmp_path, n_lat, n_lon, material, 96, 80, 2)
+    desc, cam = s.describe()
+    assert desc.n_triangles == n_tri == 2 * n_lat * n_lon - 2 * n_lon
+    dev = s.upload()
+    culled, st_c = dev.render(cam, rt.make_options(seed=3))
+    full, st_f = dev.render(cam, rt.make_options(seed=3, cluster_culling=False))
+    assert same_bits(culled, full), f"{(culled != full).any(axis=2).sum()} pixels differ"
+    assert st_c.triangle_tests < st_f.triangle_tests / 8
+    rng = np.random.default_rng(1)
+    pixels = rng.choice(cam.width * cam.height, 300, replace=False).astype(np.uint32)
+    ref, _, _, _ = ob.render_pixels(desc, cam, ob.options(seed=3), pixels)
+    assert same_bits(culled.reshape(-1, 3)[pixels], ref)
+
+
+def test_large_mesh_probes(tmp_path):
+    s, _ = scene_with_mesh(tmp_path, 100, 200, rt.DIFFUSE, 32, 32, 1)
+    desc, _ = s.describe()
+    dev = s.upload()
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-35, 35, (600, 3)).astype(np.float32)
+    d = (rng.uniform(-10, 10, (600, 3)) + np.array([0, 2, 8]) - o)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    for culling in (True, False):
+        opt = rt.make_options(cluster_culling=culling)
+        t, sid, tid, abg = dev.cast(opt, o, d)
+        rt_, rsid, rtid, rabg = ob.cast(desc, ob.from_rt_options(opt), o, d)
+        assert (rtid >= 0).sum() > 200
+        assert np.array_equal(tid, rtid) and np.array_equal(sid, rsid) and same_bits(t, rt_)
+        assert same_bits(abg[rtid >= 0], rabg[rtid >= 0])
