@@ -71,8 +71,9 @@ constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none
 constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
 constexpr uint32_t kMaxLights = 64;
 constexpr uint32_t kClusterPairs = 32;      // triangle pairs per culling cluster (64 triangles)
-constexpr uint32_t kMaxClusters = 1024;     // larger meshes get larger clusters
-constexpr size_t kClusterListBudget = size_t(8) << 30; // bytes for the per-cluster ray lists
+constexpr uint32_t kGroupClusters = 64;     // clusters per group (second level of the culling hierarchy)
+constexpr uint32_t kMaxClusters = kGroupClusters * 64; // 4096 clusters = 262 144 triangles; larger meshes get larger clusters
+constexpr size_t kClusterListBudget = size_t(24) << 30; // most bytes the per-cluster ray lists may take (of 288 GB)
 
 constexpr uint32_t F_ALIVE = 1u;   // the path still bounces
 constexpr uint32_t F_PENDING = 2u; // pend[] holds light contributions of the last hit
@@ -93,15 +94,15 @@ struct DeviceScene {
                               // each as (value of 2j, value of 2j+1); k_mesh streams this one
     const uint32_t* tri_orig; // caller's index of the triangle at each position of tri_pair
                               // (triangles are stored in Morton order of their centroids)
-    const float4* cl_min;     // padded bounds of each cluster of cluster_pairs consecutive pairs
-    const float4* cl_max;
-    const float2* cl_pair;    // 6 per PAIR of clusters (2k, 2k+1): lo.x lo.y lo.z hi.x hi.y hi.z
+    const float2* cl_pair;    // padded bounds of each cluster of cluster_pairs consecutive pairs,
+                              // 6 per PAIR of clusters (2k, 2k+1): lo.x lo.y lo.z hi.x hi.y hi.z
+    const float2* grp_pair;   // the same for groups of kGroupClusters consecutive clusters (meshes of more than 64 clusters)
     const float4* tri_shade;  // 3 per triangle: n0.xyz material | n1.xyz - | n2.xyz -
     const float4* box_min;
     const float4* box_max;
     const float4* light;      // position.xyz, intensity
     uint32_t n_spheres, n_triangles, n_boxes, n_lights;
-    uint32_t n_clusters, cluster_pairs;
+    uint32_t n_clusters, cluster_pairs, n_groups;
 };
 
 // Per-batch path state and queues.
@@ -120,6 +121,9 @@ struct Work {
     uint32_t* cl_count;      // n_clusters counters per slot
     uint32_t* cl_first;      // n_clusters + 1 job prefix sums per slot
     uint32_t* cl_list;       // n_clusters lists of list_capacity queue positions (reused by every slot)
+    uint32_t* grp_count;     // the same three for the groups of clusters
+    uint32_t* grp_first;
+    uint32_t* grp_list;
     uint32_t list_capacity;  // = rays binned per tile
 };
 
@@ -533,136 +537,141 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
 // The reference tests every triangle once any object box is hit
 // (src/raytrace.cu:136-148).  A triangle can only be hit by a ray that passes
 // through the (padded) bounds of the cluster of 64 spatially adjacent
-// triangles it belongs to, before the ray's cut-off distance.  k_bin lists, per
-// cluster, the queued rays that do; k_plan turns the list lengths into job
+// triangles it belongs to, before the ray's cut-off distance.  k_bin64 lists,
+// per cluster, the queued rays that do; k_plan turns the list lengths into job
 // offsets; k_mesh_clusters runs the same pair scan as k_mesh over each
-// cluster's list.  The image is the exhaustive scan's, bit for bit, unless the
+// cluster's list.  A mesh of more than 64 clusters gets a second level: groups
+// of 64 consecutive clusters (neighbours in space, the triangles being in
+// Morton order) with the union of their bounds; k_bin64 lists the rays per
+// group and k_bin_groups bins each group's list into its clusters, so a ray
+// is tested against 64 boxes per level instead of against every cluster --
+// a 64-ary bounding-volume hierarchy walked breadth first.  The image is the exhaustive scan's, bit for bit, unless the
 // reference's own rounding makes it accept a triangle for a ray that misses
 // the triangle by more than the padding (a grazing ray whose barycentrics are
 // rounding noise); rt_options.cluster_culling = 0 selects the exhaustive scan.
 
-// Slab test of a ray against padded cluster bounds, up to the ray's cut-off
-// distance.  fminf/fmaxf drop the NaN of 0 * inf (origin on a slab plane,
-// direction parallel to it), which errs on the side of "touches".
-__device__ __forceinline__ bool touches(float4 lo, float4 hi, float4 o4, float ix, float iy, float iz, float cutoff) {
-    const float ax = (lo.x - o4.x) * ix, bx = (hi.x - o4.x) * ix;
-    const float ay = (lo.y - o4.y) * iy, by = (hi.y - o4.y) * iy;
-    const float az = (lo.z - o4.z) * iz, bz = (hi.z - o4.z) * iz;
-    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    return t_out >= fmaxf(t_in, 0.f) && t_in <= cutoff;
-}
-
-// Two passes over the clusters per block of 256 rays: count the touching rays
-// per (cluster, wavefront) in LDS, reserve list space with ONE atomic per
-// cluster and workgroup, then write the queue positions.
-__global__ __launch_bounds__(kBlock) void k_bin(DeviceScene sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
-                                                uint32_t first_block, uint32_t blocks_in_tile,
-                                                uint32_t* __restrict__ cl_count, uint32_t* __restrict__ cl_list, uint32_t list_capacity) {
-    __shared__ uint32_t slot[kMaxClusters][kWavesPerBlock]; // counts, then list offsets
-    const ShardMap map = load_shard_map(q_count);
-    const uint32_t end = min(first_block + blocks_in_tile, map.n_ray_blocks);
-    const uint32_t lane = __lane_id();
-    const uint32_t wave = threadIdx.x >> 6;
-    for (uint32_t ray_block = first_block + blockIdx.x; ray_block < end; ray_block += gridDim.x) {
-        bool active;
-        const uint32_t at = ray_position(map, ray_block, shard_capacity, active);
-        const float4 o4 = q_o[at];
-        const float4 d4 = q_d[at];
-        const float ix = 1.f / d4.x, iy = 1.f / d4.y, iz = 1.f / d4.z; // +-inf for an axis-parallel ray
-        for (uint32_t c = 0; c < sc.n_clusters; c++) {
-            const bool touch = active && touches(sc.cl_min[c], sc.cl_max[c], o4, ix, iy, iz, d4.w);
-            const unsigned long long mask = __ballot(touch);
-            if (lane == 0) slot[c][wave] = (uint32_t)__popcll(mask);
-        }
-        __syncthreads();
-        for (uint32_t c = threadIdx.x; c < sc.n_clusters; c += kBlock) {
-            uint32_t n[kWavesPerBlock], total = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < kWavesPerBlock; k++) { n[k] = slot[c][k]; total += n[k]; }
-            uint32_t base = total ? atomicAdd(&cl_count[c * kCountStride], total) : 0;
-#pragma unroll
-            for (uint32_t k = 0; k < kWavesPerBlock; k++) { slot[c][k] = base; base += n[k]; }
-        }
-        __syncthreads();
-        for (uint32_t c = 0; c < sc.n_clusters; c++) {
-            const bool touch = active && touches(sc.cl_min[c], sc.cl_max[c], o4, ix, iy, iz, d4.w);
-            const unsigned long long mask = __ballot(touch);
-            if (touch) cl_list[(size_t)c * list_capacity + slot[c][wave] + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL))] = at;
-        }
-        __syncthreads();
+// Index of the last entry of first[0..n) that is <= job (entries are
+// non-decreasing; empty ranges share their successor's value).
+__device__ __forceinline__ uint32_t owner_of_job(const uint32_t* first, uint32_t n, uint32_t job) {
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) / 2;
+        if (first[mid] <= job) lo = mid; else hi = mid - 1;
     }
+    return lo;
 }
 
-// The same binning for meshes of at most 64 clusters, in one pass over the
-// clusters: a lane keeps the clusters its ray touches as a 64-bit mask, the
-// workgroup counts per cluster in LDS, reserves list space with one atomic per
-// cluster, and every lane then walks the set bits of its mask.  Two clusters
-// are tested per iteration; the slab parameters come from packed FMAs
+// Bins one ray per lane (queue position `at`, ignored when !active) against
+// up to 64 padded boxes and appends `at` to the list of every box the ray
+// enters before its cut-off distance.  One pass over the boxes: a lane keeps
+// the boxes its ray touches as a 64-bit mask, the workgroup counts per box in
+// LDS (`slot`, 64 words), reserves list space with one atomic per box, and
+// every lane then walks the set bits of its mask.  Two boxes are tested per
+// iteration; the slab parameters come from packed FMAs
 // (t = bound * (1/u) - origin * (1/u)), which is only a filter and need not
-// follow the reference's rounding.
-__global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ cl_pair, uint32_t n_clusters,
+// follow the reference's rounding.  All threads of the workgroup must call it.
+__device__ __forceinline__ void bin_rays64(const f2* __restrict__ box_pair, uint32_t n_boxes, bool active, uint32_t at,
+                                           const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                           uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity,
+                                           uint32_t* slot) {
+    if (threadIdx.x < 64) slot[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lane = __lane_id();
+    const uint32_t n_pairs = (n_boxes + 1) / 2;
+    const float4 o4 = q_o[at];
+    const float4 d4 = q_d[at];
+    const float ix = 1.f / d4.x, iy = 1.f / d4.y, iz = 1.f / d4.z; // +-inf for an axis-parallel ray
+    const float ox = o4.x * ix, oy = o4.y * iy, oz = o4.z * iz;
+    unsigned long long mine = 0;
+    for (uint32_t k = 0; k < n_pairs; k++) {
+        const f2* __restrict__ b = box_pair + 6 * (size_t)k;
+        // NaN (inf - inf on an axis-parallel ray) is dropped by fminf/fmaxf: errs towards "touches"
+        const f2 ax = __builtin_elementwise_fma(b[0], (f2)(ix), (f2)(-ox)), bx = __builtin_elementwise_fma(b[3], (f2)(ix), (f2)(-ox));
+        const f2 ay = __builtin_elementwise_fma(b[1], (f2)(iy), (f2)(-oy)), by = __builtin_elementwise_fma(b[4], (f2)(iy), (f2)(-oy));
+        const f2 az = __builtin_elementwise_fma(b[2], (f2)(iz), (f2)(-oz)), bz = __builtin_elementwise_fma(b[5], (f2)(iz), (f2)(-oz));
+        const float in0 = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
+        const float out0 = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
+        const float in1 = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
+        const float out1 = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
+        const bool t0 = active && out0 >= fmaxf(in0, 0.f) && in0 <= d4.w;
+        // an odd box count leaves the second half of the last entry without a box
+        const bool t1 = active && 2 * k + 1 < n_boxes && out1 >= fmaxf(in1, 0.f) && in1 <= d4.w;
+        const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1);
+        if (lane == 0) {
+            if (m0) atomicAdd(&slot[2 * k], (uint32_t)__popcll(m0));
+            if (m1) atomicAdd(&slot[2 * k + 1], (uint32_t)__popcll(m1));
+        }
+        mine |= ((unsigned long long)t0 << (2 * k)) | ((unsigned long long)t1 << (2 * k + 1));
+    }
+    __syncthreads();
+    if (threadIdx.x < n_boxes) {
+        const uint32_t total = slot[threadIdx.x];
+        slot[threadIdx.x] = total ? atomicAdd(&count[threadIdx.x * kCountStride], total) : 0;
+    }
+    __syncthreads();
+    while (mine) {
+        const uint32_t c = (uint32_t)__ffsll((long long)mine) - 1u;
+        mine &= mine - 1;
+        list[(size_t)c * list_capacity + atomicAdd(&slot[c], 1u)] = at;
+    }
+    __syncthreads();
+}
+
+// First level: the queued rays of one tile (256-ray blocks [first_block,
+// first_block + blocks_in_tile)) against the clusters of a mesh of at most 64
+// clusters, or against the groups of a larger one.
+__global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ box_pair, uint32_t n_boxes,
                                                   const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                   const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
                                                   uint32_t first_block, uint32_t blocks_in_tile,
-                                                  uint32_t* __restrict__ cl_count, uint32_t* __restrict__ cl_list, uint32_t list_capacity) {
-    __shared__ uint32_t slot[64]; // counts, then next free list position
+                                                  uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity) {
+    __shared__ uint32_t slot[64];
     const ShardMap map = load_shard_map(q_count);
     const uint32_t end = min(first_block + blocks_in_tile, map.n_ray_blocks);
-    const uint32_t lane = __lane_id();
-    const uint32_t n_pairs = (n_clusters + 1) / 2;
     for (uint32_t ray_block = first_block + blockIdx.x; ray_block < end; ray_block += gridDim.x) {
-        if (threadIdx.x < 64) slot[threadIdx.x] = 0;
-        __syncthreads();
         bool active;
         const uint32_t at = ray_position(map, ray_block, shard_capacity, active);
-        const float4 o4 = q_o[at];
-        const float4 d4 = q_d[at];
-        const float ix = 1.f / d4.x, iy = 1.f / d4.y, iz = 1.f / d4.z; // +-inf for an axis-parallel ray
-        const float ox = o4.x * ix, oy = o4.y * iy, oz = o4.z * iz;
-        unsigned long long mine = 0;
-        for (uint32_t k = 0; k < n_pairs; k++) {
-            const f2* __restrict__ b = cl_pair + 6 * (size_t)k;
-            // NaN (inf - inf on an axis-parallel ray) is dropped by fminf/fmaxf: errs towards "touches"
-            const f2 ax = __builtin_elementwise_fma(b[0], (f2)(ix), (f2)(-ox)), bx = __builtin_elementwise_fma(b[3], (f2)(ix), (f2)(-ox));
-            const f2 ay = __builtin_elementwise_fma(b[1], (f2)(iy), (f2)(-oy)), by = __builtin_elementwise_fma(b[4], (f2)(iy), (f2)(-oy));
-            const f2 az = __builtin_elementwise_fma(b[2], (f2)(iz), (f2)(-oz)), bz = __builtin_elementwise_fma(b[5], (f2)(iz), (f2)(-oz));
-            const float in0 = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
-            const float out0 = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
-            const float in1 = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
-            const float out1 = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
-            const bool t0 = active && out0 >= fmaxf(in0, 0.f) && in0 <= d4.w;
-            // an odd cluster count leaves the second half of the last entry without a cluster
-            const bool t1 = active && 2 * k + 1 < n_clusters && out1 >= fmaxf(in1, 0.f) && in1 <= d4.w;
-            const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1);
-            if (lane == 0) {
-                if (m0) atomicAdd(&slot[2 * k], (uint32_t)__popcll(m0));
-                if (m1) atomicAdd(&slot[2 * k + 1], (uint32_t)__popcll(m1));
-            }
-            mine |= ((unsigned long long)t0 << (2 * k)) | ((unsigned long long)t1 << (2 * k + 1));
-        }
-        __syncthreads();
-        if (threadIdx.x < n_clusters) {
-            const uint32_t total = slot[threadIdx.x];
-            slot[threadIdx.x] = total ? atomicAdd(&cl_count[threadIdx.x * kCountStride], total) : 0;
-        }
-        __syncthreads();
-        while (mine) {
-            const uint32_t c = (uint32_t)__ffsll((long long)mine) - 1u;
-            mine &= mine - 1;
-            cl_list[(size_t)c * list_capacity + atomicAdd(&slot[c], 1u)] = at;
-        }
-        __syncthreads();
+        bin_rays64(box_pair, n_boxes, active, at, q_o, q_d, count, list, list_capacity, slot);
     }
 }
 
-// cl_first[c] = number of 256-ray jobs of the clusters before c; cl_first[n] = total.
-__global__ __launch_bounds__(1024) void k_plan(const uint32_t* __restrict__ cl_count, uint32_t n_clusters, uint32_t* __restrict__ cl_first) {
+// Second level: the rays on each group's list against the (at most 64)
+// clusters of that group.  A job is 256 list entries of one group; grp_first
+// holds the job prefix sums k_plan made of the group counts.
+__global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl_pair, uint32_t n_clusters, uint32_t n_groups,
+                                                       const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                       const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_first,
+                                                       const uint32_t* __restrict__ grp_list,
+                                                       uint32_t* __restrict__ cl_count, uint32_t* __restrict__ cl_list, uint32_t list_capacity) {
+    __shared__ uint32_t slot[64];
+    __shared__ uint32_t first_job[64 + 1];
+    if (threadIdx.x <= n_groups) first_job[threadIdx.x] = grp_first[threadIdx.x];
+    __syncthreads();
+    const uint32_t n_jobs = first_job[n_groups];
+    for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+        const uint32_t g = owner_of_job(first_job, n_groups, job);
+        const uint32_t count = grp_count[g * kCountStride];
+        const uint32_t e = (job - first_job[g]) * kBlock + threadIdx.x;
+        const bool active = e < count;
+        const uint32_t at = grp_list[(size_t)g * list_capacity + (active ? e : count - 1)];
+        const uint32_t first_cluster = g * kGroupClusters;
+        bin_rays64(cl_pair + 6 * (size_t)(first_cluster / 2), min(kGroupClusters, n_clusters - first_cluster), active, at, q_o, q_d,
+                   cl_count + (size_t)first_cluster * kCountStride, cl_list + (size_t)first_cluster * list_capacity, list_capacity, slot);
+    }
+}
+
+// first[i] = number of 256-entry jobs of the lists before i; first[n] = total.  n <= 4096.
+__global__ __launch_bounds__(1024) void k_plan(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ first) {
     __shared__ uint32_t scan[1024];
     const uint32_t t = threadIdx.x;
-    const uint32_t jobs = t < n_clusters ? (cl_count[t * kCountStride] + kBlock - 1) / kBlock : 0;
-    scan[t] = jobs;
+    const uint32_t per = (n + 1023) / 1024; // consecutive lists per thread, at most 4
+    uint32_t jobs[4] = {0, 0, 0, 0}, mine = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = t * per + k;
+        jobs[k] = i < n ? (count[i * kCountStride] + kBlock - 1) / kBlock : 0;
+        mine += jobs[k];
+    }
+    scan[t] = mine;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
         const uint32_t v = t >= off ? scan[t - off] : 0;
@@ -670,8 +679,13 @@ __global__ __launch_bounds__(1024) void k_plan(const uint32_t* __restrict__ cl_c
         scan[t] += v;
         __syncthreads();
     }
-    if (t < n_clusters) cl_first[t] = scan[t] - jobs;
-    if (t == 1023) cl_first[n_clusters] = scan[1023];
+    uint32_t run = scan[t] - mine;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = t * per + k;
+        if (i < n) first[i] = run;
+        run += jobs[k];
+    }
+    if (t == 1023) first[n] = scan[1023];
 }
 
 __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
@@ -686,13 +700,7 @@ __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__
     const uint32_t n_jobs = first_job[n_clusters];
     const uint32_t n_pairs = (n_tri + 1) / 2;
     for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
-        // the last cluster whose first job is <= job (empty clusters share their successor's value)
-        uint32_t lo = 0, hi = n_clusters - 1;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) / 2;
-            if (first_job[mid] <= job) lo = mid; else hi = mid - 1;
-        }
-        const uint32_t c = lo;
+        const uint32_t c = owner_of_job(first_job, n_clusters, job);
         const uint32_t count = cl_count[c * kCountStride];
         const uint32_t e = (job - first_job[c]) * kBlock + threadIdx.x;
         const bool active = e < count;
@@ -1242,12 +1250,14 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t queue_entries = shard_capacity * kShards;
     if (queue_entries > 0xffffffffu) { rt_set_error("batch too large for the ray queue"); return RT_ERR_INVALID; }
     // cluster lists: one tile of rays at a time if the whole queue would not fit the budget
-    const size_t nc = s->d.n_clusters;
+    const size_t nc = s->d.n_clusters, ng = s->d.n_groups;
     size_t list_capacity = 0, tiles = 1;
     if (nc > 1) {
         // a tile is a range of 256-ray blocks; every shard may end in a partial block
         const size_t max_blocks = ((shard_capacity + kBlock - 1) / kBlock) * kShards;
-        list_capacity = kClusterListBudget / (4 * nc) / kBlock * kBlock;
+        size_t budget = kClusterListBudget, free_bytes = 0, total_bytes = 0;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && free_bytes / 4 < budget) budget = free_bytes / 4;
+        list_capacity = budget / (4 * (nc + ng)) / kBlock * kBlock;
         if (list_capacity > max_blocks * kBlock) list_capacity = max_blocks * kBlock;
         if (list_capacity < kBlock) list_capacity = kBlock;
         tiles = (max_blocks + list_capacity / kBlock - 1) / (list_capacity / kBlock);
@@ -1260,7 +1270,9 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
         (rc = work_alloc(s, &s->w.q_o, queue_entries)) || (rc = work_alloc(s, &s->w.q_d, queue_entries)) ||
         (rc = work_alloc(s, &s->w.q_count, (size_t)n_counters * kShards * kCountStride)) ||
         (rc = work_alloc(s, &s->w.cl_count, slots_cl * nc * kCountStride)) || (rc = work_alloc(s, &s->w.cl_first, slots_cl * (nc + 1))) ||
-        (rc = work_alloc(s, &s->w.cl_list, nc * list_capacity))) {
+        (rc = work_alloc(s, &s->w.cl_list, nc * list_capacity)) ||
+        (rc = work_alloc(s, &s->w.grp_count, slots_cl * ng * kCountStride)) || (rc = work_alloc(s, &s->w.grp_first, slots_cl * (ng + 1))) ||
+        (rc = work_alloc(s, &s->w.grp_list, ng * list_capacity))) {
         free_work(s);
         return rc;
     }
@@ -1316,14 +1328,24 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
             uint32_t* cl_count = s->w.cl_count + slot * nc * kCountStride;
             uint32_t* cl_first = s->w.cl_first + slot * (nc + 1);
             if ((rc = mark('B')) != RT_OK) return rc;
-            if (nc <= 64)
-                hipLaunchKernelGGL(k_bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.cl_pair), nc,
+            const f2* cl_pair = reinterpret_cast<const f2*>(s->d.cl_pair);
+            if (s->d.n_groups == 0) {
+                hipLaunchKernelGGL(k_bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
                                    tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list, s->w.list_capacity);
-            else
-                hipLaunchKernelGGL(k_bin, dim3(kMeshGrid), dim3(kBlock), 0, stream, s->d, (const float4*)s->w.q_o, (const float4*)s->w.q_d,
-                                   q_count, s->w.shard_capacity, tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list,
+            } else {
+                const uint32_t ng = s->d.n_groups;
+                uint32_t* grp_count = s->w.grp_count + slot * ng * kCountStride;
+                uint32_t* grp_first = s->w.grp_first + slot * (ng + 1);
+                hipLaunchKernelGGL(k_bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
+                                   (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
+                                   tile * blocks_per_tile, blocks_per_tile, grp_count, s->w.grp_list, s->w.list_capacity);
+                hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)grp_count, ng, grp_first);
+                hipLaunchKernelGGL(k_bin_groups, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc, ng,
+                                   (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)grp_count,
+                                   (const uint32_t*)grp_first, (const uint32_t*)s->w.grp_list, cl_count, s->w.cl_list,
                                    s->w.list_capacity);
+            }
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cl_count, nc, cl_first);
             if ((rc = mark('M')) != RT_OK) return rc;
             hipLaunchKernelGGL(k_mesh_clusters, dim3(kMeshGrid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
@@ -1485,6 +1507,23 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
             if (c & 1) dst.y = v[k]; else dst.x = v[k];
         }
     }
+    // groups of kGroupClusters consecutive clusters with the union of their bounds
+    const uint32_t n_groups = n_clusters > 64 ? (n_clusters + kGroupClusters - 1) / kGroupClusters : 0;
+    std::vector<float2> grp_pair(6 * (((size_t)n_groups + 1) / 2), make_float2(0.f, 0.f));
+    for (uint32_t g = 0; g < n_groups; g++) {
+        float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t c = g * kGroupClusters; c < std::min(n_clusters, (g + 1) * kGroupClusters); c++) {
+            const float lo[3] = {cl_min[c].x, cl_min[c].y, cl_min[c].z}, hi[3] = {cl_max[c].x, cl_max[c].y, cl_max[c].z};
+            for (int a = 0; a < 3; a++) {
+                if (lo[a] < v[a]) v[a] = lo[a];
+                if (hi[a] > v[3 + a]) v[3 + a] = hi[a];
+            }
+        }
+        for (int k = 0; k < 6; k++) {
+            float2& dst = grp_pair[6 * (size_t)(g / 2) + k];
+            if (g & 1) dst.y = v[k]; else dst.x = v[k];
+        }
+    }
     std::vector<float4> box_min(d->n_boxes), box_max(d->n_boxes), light(d->n_lights);
     for (uint32_t i = 0; i < d->n_boxes; i++) {
         box_min[i] = make_float4(d->box_min[3 * i], d->box_min[3 * i + 1], d->box_min[3 * i + 2], 0.f);
@@ -1500,11 +1539,12 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     s->d.n_lights = d->n_lights;
     s->d.n_clusters = n_clusters;
     s->d.cluster_pairs = cluster_pairs;
+    s->d.n_groups = n_groups;
     s->cluster_tris = cluster_tris;
     if ((rc = upload(s, sphere, &s->d.sphere)) || (rc = upload(s, sphere_mat, &s->d.sphere_mat)) ||
         (rc = upload(s, mat_color, &s->d.mat_color)) || (rc = upload(s, mat_ior, &s->d.mat_ior)) ||
         (rc = upload(s, geom, &s->d.tri_geom)) || (rc = upload(s, pair, &s->d.tri_pair)) || (rc = upload(s, orig, &s->d.tri_orig)) ||
-        (rc = upload(s, cl_min, &s->d.cl_min)) || (rc = upload(s, cl_max, &s->d.cl_max)) || (rc = upload(s, cl_pair, &s->d.cl_pair)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
+        (rc = upload(s, cl_pair, &s->d.cl_pair)) || (rc = upload(s, grp_pair, &s->d.grp_pair)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
         (rc = upload(s, box_min, &s->d.box_min)) || (rc = upload(s, box_max, &s->d.box_max)) ||
         (rc = upload(s, light, &s->d.light))) {
         rt_scene_free(s);
@@ -1574,6 +1614,8 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         const dim3 grid((f.n_paths + kBlock - 1) / kBlock), block(kBlock);
         HIP_TRY(hipMemsetAsync(s->w.q_count, 0, counts.size() * sizeof(uint32_t), stream));
         if (cull) HIP_TRY(hipMemsetAsync(s->w.cl_count, 0, cl_words * sizeof(uint32_t), stream));
+        if (cull && s->d.n_groups)
+            HIP_TRY(hipMemsetAsync(s->w.grp_count, 0, (size_t)n_counters * s->tiles * s->d.n_groups * kCountStride * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_generate, grid, block, 0, stream, s->d, s->w, f);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
@@ -1705,6 +1747,7 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
         hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, s->w, f, (const float*)d_a, (const float*)d_b, as_segments);
         const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
         if (cull && hipMemset(s->w.cl_count, 0, (size_t)2 * s->tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        if (cull && s->d.n_groups && hipMemset(s->w.grp_count, 0, (size_t)2 * s->tiles * s->d.n_groups * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         if (launch_mesh(s, 0, nullptr, false, cull) != RT_OK) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, s->w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }
