@@ -561,57 +561,73 @@ __device__ __forceinline__ uint32_t owner_of_job(const uint32_t* first, uint32_t
     return lo;
 }
 
+// The hardware minimum / maximum: a NaN operand is dropped (minNum / maxNum).
+// Written as instructions because the library functions first re-quiet every
+// operand (v_max x, x), which doubles the cost of a slab test.
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Slab tests of one ray against box pairs [first, last), last - first <= 16:
+// bit 2(k - first) + h of the result is set when the ray enters box h of pair
+// k before its cut-off distance.  The slab parameters come from packed FMAs
+// (t = bound * (1/u) - origin * (1/u)); this is only a filter and need not
+// follow the reference's rounding.  NaN (inf - inf on an axis-parallel ray) is
+// dropped by the minimum / maximum, which errs towards "touches".
+__device__ __forceinline__ uint32_t slab_bits(const f2* __restrict__ box_pair, uint32_t first, uint32_t last, float ix, float iy, float iz,
+                                              float ox, float oy, float oz, float cutoff) {
+    uint32_t bits = 0;
+    for (uint32_t k = first; k < last; k++) {
+        const f2* __restrict__ b = box_pair + 6 * (size_t)k;
+        const f2 ax = __builtin_elementwise_fma(b[0], (f2)(ix), (f2)(-ox)), bx = __builtin_elementwise_fma(b[3], (f2)(ix), (f2)(-ox));
+        const f2 ay = __builtin_elementwise_fma(b[1], (f2)(iy), (f2)(-oy)), by = __builtin_elementwise_fma(b[4], (f2)(iy), (f2)(-oy));
+        const f2 az = __builtin_elementwise_fma(b[2], (f2)(iz), (f2)(-oz)), bz = __builtin_elementwise_fma(b[5], (f2)(iz), (f2)(-oz));
+        const float in0 = hw_max3(hw_min(ax.x, bx.x), hw_min(ay.x, by.x), hw_min(az.x, bz.x));
+        const float out0 = hw_min3(hw_max(ax.x, bx.x), hw_max(ay.x, by.x), hw_max(az.x, bz.x));
+        const float in1 = hw_max3(hw_min(ax.y, bx.y), hw_min(ay.y, by.y), hw_min(az.y, bz.y));
+        const float out1 = hw_min3(hw_max(ax.y, bx.y), hw_max(ay.y, by.y), hw_max(az.y, bz.y));
+        const bool t0 = (out0 >= hw_max(in0, 0.f)) & (in0 <= cutoff);
+        const bool t1 = (out1 >= hw_max(in1, 0.f)) & (in1 <= cutoff);
+        const uint32_t bit = 1u << (2 * (k - first)); // wave-uniform
+        bits |= (t0 ? bit : 0u) | (t1 ? bit << 1 : 0u);
+    }
+    return bits;
+}
+
 // Bins one ray per lane (queue position `at`, ignored when !active) against
 // up to 64 padded boxes and appends `at` to the list of every box the ray
 // enters before its cut-off distance.  One pass over the boxes: a lane keeps
-// the boxes its ray touches as a 64-bit mask, the workgroup counts per box in
-// LDS (`slot`, 64 words), reserves list space with one atomic per box, and
-// every lane then walks the set bits of its mask.  Two boxes are tested per
-// iteration; the slab parameters come from packed FMAs
-// (t = bound * (1/u) - origin * (1/u)), which is only a filter and need not
-// follow the reference's rounding.  All threads of the workgroup must call it.
+// the boxes its ray touches as a 64-bit mask; then every lane walks the set
+// bits of its mask twice -- to count per box in LDS (`slot`, 64 words), and,
+// after the workgroup has reserved list space with one atomic per box, to
+// take its positions.  All threads of the workgroup must call it.
 __device__ __forceinline__ void bin_rays64(const f2* __restrict__ box_pair, uint32_t n_boxes, bool active, uint32_t at,
                                            const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                            uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity,
                                            uint32_t* slot) {
     if (threadIdx.x < 64) slot[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t lane = __lane_id();
     const uint32_t n_pairs = (n_boxes + 1) / 2;
     const float4 o4 = q_o[at];
     const float4 d4 = q_d[at];
     const float ix = 1.f / d4.x, iy = 1.f / d4.y, iz = 1.f / d4.z; // +-inf for an axis-parallel ray
     const float ox = o4.x * ix, oy = o4.y * iy, oz = o4.z * iz;
-    unsigned long long mine = 0;
-    for (uint32_t k = 0; k < n_pairs; k++) {
-        const f2* __restrict__ b = box_pair + 6 * (size_t)k;
-        // NaN (inf - inf on an axis-parallel ray) is dropped by fminf/fmaxf: errs towards "touches"
-        const f2 ax = __builtin_elementwise_fma(b[0], (f2)(ix), (f2)(-ox)), bx = __builtin_elementwise_fma(b[3], (f2)(ix), (f2)(-ox));
-        const f2 ay = __builtin_elementwise_fma(b[1], (f2)(iy), (f2)(-oy)), by = __builtin_elementwise_fma(b[4], (f2)(iy), (f2)(-oy));
-        const f2 az = __builtin_elementwise_fma(b[2], (f2)(iz), (f2)(-oz)), bz = __builtin_elementwise_fma(b[5], (f2)(iz), (f2)(-oz));
-        const float in0 = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
-        const float out0 = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
-        const float in1 = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
-        const float out1 = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
-        const bool t0 = active && out0 >= fmaxf(in0, 0.f) && in0 <= d4.w;
-        // an odd box count leaves the second half of the last entry without a box
-        const bool t1 = active && 2 * k + 1 < n_boxes && out1 >= fmaxf(in1, 0.f) && in1 <= d4.w;
-        const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1);
-        if (lane == 0) {
-            if (m0) atomicAdd(&slot[2 * k], (uint32_t)__popcll(m0));
-            if (m1) atomicAdd(&slot[2 * k + 1], (uint32_t)__popcll(m1));
-        }
-        mine |= ((unsigned long long)t0 << (2 * k)) | ((unsigned long long)t1 << (2 * k + 1));
-    }
+    // boxes 0-31 and 32-63 this lane's ray touches
+    const uint32_t bits_lo = slab_bits(box_pair, 0, min(n_pairs, 16u), ix, iy, iz, ox, oy, oz, d4.w);
+    const uint32_t bits_hi = n_pairs > 16 ? slab_bits(box_pair, 16, n_pairs, ix, iy, iz, ox, oy, oz, d4.w) : 0u;
+    // an odd box count leaves the second half of the last entry without a box: drop its bit
+    const unsigned long long real = n_boxes >= 64 ? ~0ULL : (1ULL << n_boxes) - 1ULL;
+    const unsigned long long mine = active ? ((((unsigned long long)bits_hi << 32) | bits_lo) & real) : 0ULL;
+    for (unsigned long long m = mine; m; m &= m - 1) atomicAdd(&slot[(uint32_t)__ffsll((long long)m) - 1u], 1u);
     __syncthreads();
     if (threadIdx.x < n_boxes) {
         const uint32_t total = slot[threadIdx.x];
         slot[threadIdx.x] = total ? atomicAdd(&count[threadIdx.x * kCountStride], total) : 0;
     }
     __syncthreads();
-    while (mine) {
-        const uint32_t c = (uint32_t)__ffsll((long long)mine) - 1u;
-        mine &= mine - 1;
+    for (unsigned long long m = mine; m; m &= m - 1) {
+        const uint32_t c = (uint32_t)__ffsll((long long)m) - 1u;
         list[(size_t)c * list_capacity + atomicAdd(&slot[c], 1u)] = at;
     }
     __syncthreads();
