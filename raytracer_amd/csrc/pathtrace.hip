@@ -332,34 +332,47 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // win ties, src/raytrace.cu:203-212, and a shadow ray asks for t < distance,
 // :240).  Once a triangle is held, `t` is its distance to within a few 1e-7
 // (relative) and the exact value is the IEEE quotient num / den, which
-// hit_distance() evaluates once, after the scan.
+// hit_distance() evaluates once, after the scan.  `index` is the triangle's
+// POSITION in the scan order; tri_orig maps it to the caller's index.
 struct Nearest {
     float t, num, den;
     int index;
 };
+
+// tri_orig[pos] through the vector memory path.  `pos` is wave-uniform inside
+// the scan, so the compiler would use a scalar load, and waiting for a scalar
+// load also waits for the prefetch of the next triangle pair (scalar loads
+// return out of order: the only wait is "all of them").  Used on the rare
+// exact-tie path only.
+__device__ __forceinline__ int orig_index(const uint32_t* __restrict__ tri_orig, int pos) {
+    const uint32_t* p = tri_orig + pos;
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return (int)v;
+}
 
 __device__ __forceinline__ Nearest nearest_init(float cutoff) { Nearest n; n.t = cutoff; n.num = 0.f; n.den = 1.f; n.index = -1; return n; }
 __device__ __forceinline__ float hit_distance(const Nearest& n) { return n.num / n.den; }
 
 // Exact comparison (reference src/raytrace.cu:164-174): t = (A-O).N / u.N must
 // be positive and nearer than the nearest so far; among equal distances the
-// lower triangle index wins, as in the reference's in-order scan.
-__device__ __forceinline__ void take_if_nearer_exact(float ao_dot_n, float d, uint32_t index, Nearest& best) {
+// lower caller's triangle index wins, as in the reference's in-order scan.
+__device__ __forceinline__ void take_if_nearer_exact(float ao_dot_n, float d, uint32_t pos, const uint32_t* __restrict__ tri_orig, Nearest& best) {
     const float t = ao_dot_n / d;
     const float held = best.index >= 0 ? hit_distance(best) : best.t;
-    if (t > 0 && (t < held || (t == held && best.index >= 0 && (int)index < best.index))) {
-        best.t = t; best.num = ao_dot_n; best.den = d; best.index = (int)index;
+    if (t > 0 && (t < held || (t == held && best.index >= 0 && orig_index(tri_orig, (int)pos) < orig_index(tri_orig, best.index)))) {
+        best.t = t; best.num = ao_dot_n; best.den = d; best.index = (int)pos;
     }
 }
 
 // Exact tail of one ray-triangle test (reference src/raytrace.cu:161-174),
 // entered only by lanes the division-free test could neither reject nor
 // accept.
-__device__ __forceinline__ void exact_hit(float nb, float ng, float d, float ao_dot_n, uint32_t index, Nearest& best) {
+__device__ __forceinline__ void exact_hit(float nb, float ng, float d, float ao_dot_n, uint32_t pos, const uint32_t* __restrict__ tri_orig, Nearest& best) {
     const float beta = nb / d;
     const float gamma = -ng / d;
     const float alpha = 1.f - beta - gamma;
-    if (alpha >= 0 && beta >= 0 && gamma >= 0) take_if_nearer_exact(ao_dot_n, d, index, best);
+    if (alpha >= 0 && beta >= 0 && gamma >= 0) take_if_nearer_exact(ao_dot_n, d, pos, tri_orig, best);
 }
 
 // A lane the division-free test could not reject.  `lo` is the smallest of the
@@ -371,17 +384,18 @@ __device__ __forceinline__ void exact_hit(float nb, float ng, float d, float ao_
 // order without a division; a negative t_ has a non-positive exact quotient.
 // Near-ties, values too small for the error bound and NaNs are decided
 // exactly.  Anything closer to an edge takes exact_hit.
-__device__ __forceinline__ void candidate(float lo, float nb, float ng, float d, float rcp, float ao_dot_n, uint32_t index, Nearest& best) {
+__device__ __forceinline__ void candidate(float lo, float nb, float ng, float d, float rcp, float ao_dot_n, uint32_t pos,
+                                          const uint32_t* __restrict__ tri_orig, Nearest& best) {
     if (lo >= 1e-5f) {
         const float t_ = ao_dot_n * rcp;
         if (t_ > best.t * 1.000002f || t_ < 0.f) return;
         if (t_ * 1.000002f < best.t && t_ > 1e-30f) {
-            best.t = t_; best.num = ao_dot_n; best.den = d; best.index = (int)index;
+            best.t = t_; best.num = ao_dot_n; best.den = d; best.index = (int)pos;
         } else {
-            take_if_nearer_exact(ao_dot_n, d, index, best);
+            take_if_nearer_exact(ao_dot_n, d, pos, tri_orig, best);
         }
     } else {
-        exact_hit(nb, ng, d, ao_dot_n, index, best);
+        exact_hit(nb, ng, d, ao_dot_n, pos, tri_orig, best);
     }
 }
 
@@ -404,7 +418,7 @@ __device__ __forceinline__ PairData load_pair(const f2* __restrict__ tri2, uint3
 // The division-free test uses an approximate reciprocal: a hit the reference
 // accepts has alpha, beta, gamma in [0, 1], where the approximations are off
 // by < 1e-6, so the 1e-5 margin never drops one; a NaN passes.
-__device__ __forceinline__ void test_pair(const PairData& p, const uint32_t* __restrict__ orig, float ox, float oy, float oz,
+__device__ __forceinline__ void test_pair(const PairData& p, const uint32_t* __restrict__ tri_orig, uint32_t pos, float ox, float oy, float oz,
                                           float ux, float uy, float uz, Nearest& best) {
     const f2 Ax = p.v[0], Ay = p.v[1], Az = p.v[2];
     const f2 e1x = p.v[3], e1y = p.v[4], e1z = p.v[5];
@@ -430,9 +444,9 @@ __device__ __forceinline__ void test_pair(const PairData& p, const uint32_t* __r
         // one divergent region for both triangles: a lane brings the first of its candidates
         // (lower position first, as in the scan), the rare second one follows
         const f2 aon = (aox * Nx + aoy * Ny) + aoz * Nz;
-        if (c0) candidate(lo0, nb.x, ng.x, d.x, rcp.x, aon.x, orig[0], best);
-        else    candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, orig[1], best);
-        if (c0 && c1) candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, orig[1], best);
+        if (c0) candidate(lo0, nb.x, ng.x, d.x, rcp.x, aon.x, pos, tri_orig, best);
+        else    candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, pos + 1, tri_orig, best);
+        if (c0 && c1) candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, pos + 1, tri_orig, best);
     }
 }
 
@@ -483,11 +497,11 @@ __device__ __forceinline__ void scan_pairs(const f2* __restrict__ tri2, const ui
         __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): `cur` has landed
         const PairData nxt = load_pair(tri2, min(j + 1, last - 1));
         __builtin_amdgcn_sched_barrier(0); // keep the request ahead of the test it overlaps
-        test_pair(cur, tri_orig + 2 * (size_t)j, ox, oy, oz, ux, uy, uz, best);
+        test_pair(cur, tri_orig, 2 * j, ox, oy, oz, ux, uy, uz, best);
         __builtin_amdgcn_s_waitcnt(0xC07F); // `nxt` has landed
         cur = load_pair(tri2, min(j + 2, last - 1));
         __builtin_amdgcn_sched_barrier(0);
-        if (j + 1 < last) test_pair(nxt, tri_orig + 2 * (size_t)j + 2, ox, oy, oz, ux, uy, uz, best);
+        if (j + 1 < last) test_pair(nxt, tri_orig, 2 * j + 2, ox, oy, oz, ux, uy, uz, best);
     }
 }
 
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
         const uint32_t first = chunk * kChunkPairs;
         scan_pairs(tri2, tri_orig, first, min(first + kChunkPairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
         if (active && best.index >= 0) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | (uint32_t)best.index;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | tri_orig[best.index];
             atomicMin(&hit[__float_as_uint(o4.w)], key);
         }
     }
@@ -727,7 +741,7 @@ __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__
         const uint32_t first = c * cluster_pairs;
         scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
         if (active && best.index >= 0) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | (uint32_t)best.index;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | tri_orig[best.index];
             atomicMin(&hit[__float_as_uint(o4.w)], key);
         }
     }
