@@ -790,56 +790,115 @@ __device__ __forceinline__ void launch_ray(const DeviceScene& sc, const Spheres&
 }
 
 // Camera sample of every path of the batch (reference src/raytrace.cu:479-494).
+//
+// With anti-aliasing the pixel offset is a Box-Muller pair that is redrawn
+// until both components are within half a pixel (src/raytrace.cu:33-42,
+// 483-486): 6.8 draws per path on average, but the slowest of 64 lanes needs
+// about 26, so a wavefront that keeps one path per lane idles three quarters
+// of its lanes.  A lane therefore owns kGenPaths paths and searches their
+// accepted draws back to back (first loop: lanes stay busy until the last
+// path of the slowest lane), and only the accepted draw of each path is
+// evaluated with the reference's arithmetic (second loop, all lanes together).
+//
+// The search classifies a draw with hardware transcendentals: r1 < 0.77 means
+// radius > 0.722, so one component exceeds 0.5 (max(|cos|,|sin|) >= 0.7071);
+// otherwise the approximate offsets (absolute error far below 1e-4) decide,
+// except within 1e-4 of the half-pixel limit, where the reference's own
+// arithmetic is evaluated.
+constexpr uint32_t kGenPaths = 4;
+
+__device__ __forceinline__ void jitter_exact(const rt_rng_key& key, uint32_t dim, float& dx, float& dy) {
+    const float r1 = rt_rng_uniform(key, dim);
+    const float r2 = rt_rng_uniform(key, dim + 1);
+    const float radius = sqrtf(-2 * rt_logf(r1));
+    const float angle = (float)(2 * M_PI * (double)r2);
+    float sn, cs;
+    rt_sincosf(angle, &sn, &cs);
+    dx = radius * cs * 1.f;
+    dy = radius * sn * 1.f;
+}
+
 __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f) {
     __shared__ float4 sphere_lds[kSphereCache];
+    __shared__ uint32_t key_kp[kGenPaths][kBlock], key_ks[kGenPaths][kBlock];
+    __shared__ uint32_t accepted[kGenPaths][kBlock]; // first dimension of the accepted draw
     const Spheres sp = stage_spheres(sc, sphere_lds);
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    const bool alive = p < f.n_paths;
-    V3 start = mk(f.pos[0], f.pos[1], f.pos[2]);
-    V3 ray = mk(0.f, 0.f, 1.f);
-    if (alive) {
-        const uint32_t pixel = path_pixel(f, p);
-        const uint32_t ux = pixel % f.width, uy = pixel / f.width;
-        const rt_rng_key key = rt_rng_make_key(f.seed, pixel, path_sample(f, p));
-        uint32_t dim = 0;
-        float dx = 0.f, dy = 0.f;
-        if (f.antialiasing) {
-            // Box-Muller pair, redrawn until both components are within half a
-            // pixel (reference src/raytrace.cu:33-42,483-486).  A draw with
-            // r1 < 0.77 has radius > 0.722 and max(|cos|,|sin|) >= 0.7071, so
-            // one component exceeds 0.5: it is rejected without evaluating the
-            // logarithm and the trigonometric pair.
-            // Such draws are skipped in a tight inner loop (one hash per draw)
-            // so that the lanes of a wavefront meet again for the expensive
-            // evaluation of a plausible draw.
-            dx = 1.f;
-            dy = 1.f;
-            while (fabsf(dx) > 0.5f || fabsf(dy) > 0.5f) {
-                float r1 = rt_rng_uniform(key, dim);
-                while (r1 < 0.77f) {
-                    dim += 2;
-                    r1 = rt_rng_uniform(key, dim);
-                }
+    const uint32_t base = blockIdx.x * (kBlock * kGenPaths) + threadIdx.x;
+    // only this lane reads what it writes to the three arrays: no barrier needed
+    uint32_t owned = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < kGenPaths; r++) {
+        const uint32_t p = base + r * kBlock;
+        if (p < f.n_paths) {
+            const rt_rng_key key = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
+            key_kp[r][threadIdx.x] = key.kp;
+            key_ks[r][threadIdx.x] = key.ks;
+            accepted[r][threadIdx.x] = 0;
+            owned = r + 1; // paths are consecutive: a lane owns slots 0 .. owned-1
+        }
+    }
+    if (f.antialiasing) {
+        uint32_t r = 0, dim = 0;
+        rt_rng_key key;
+        key.kp = key_kp[0][threadIdx.x];
+        key.ks = key_ks[0][threadIdx.x];
+        while (r < owned) {
+            const float r1 = rt_rng_uniform(key, dim);
+            bool accept = false;
+            if (r1 >= 0.77f) {
                 const float r2 = rt_rng_uniform(key, dim + 1);
+                const float radius = __builtin_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1)); // -2 ln 2 * log2(r1)
+                const float m = fmaxf(fabsf(radius * __builtin_amdgcn_cosf(r2)), fabsf(radius * __builtin_amdgcn_sinf(r2))); // argument in turns
+                if (m < 0.4999f) {
+                    accept = true;
+                } else if (!(m > 0.5001f)) {
+                    float dx, dy;
+                    jitter_exact(key, dim, dx, dy);
+                    accept = !(fabsf(dx) > 0.5f || fabsf(dy) > 0.5f);
+                }
+            }
+            if (accept) {
+                accepted[r][threadIdx.x] = dim;
+                r++;
+                dim = 0;
+                if (r < owned) {
+                    key.kp = key_kp[r][threadIdx.x];
+                    key.ks = key_ks[r][threadIdx.x];
+                }
+            } else {
                 dim += 2;
-                const float radius = sqrtf(-2 * rt_logf(r1));
-                const float angle = (float)(2 * M_PI * (double)r2);
-                float sn, cs;
-                rt_sincosf(angle, &sn, &cs);
-                dx = radius * cs * 1.f;
-                dy = radius * sn * 1.f;
             }
         }
-        const float px = (float)ux + 0.5f + dx;
-        const float py = (float)uy + 0.5f + dy;
-        const V3 dir = normalize(mk((px - f.cx) / f.fx, (py - f.cy) / f.fy, 1.f));
-        ray = mk(dot(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
-                 dot(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
-                 dot(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
-        w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
-        w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
     }
-    launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
+    for (uint32_t r = 0; r < kGenPaths; r++) {
+        const uint32_t p = base + r * kBlock;
+        const bool alive = p < f.n_paths;
+        V3 start = mk(f.pos[0], f.pos[1], f.pos[2]);
+        V3 ray = mk(0.f, 0.f, 1.f);
+        if (alive) {
+            const uint32_t pixel = path_pixel(f, p);
+            const uint32_t ux = pixel % f.width, uy = pixel / f.width;
+            uint32_t dim = 0;
+            float dx = 0.f, dy = 0.f;
+            if (f.antialiasing) {
+                rt_rng_key key;
+                key.kp = key_kp[r][threadIdx.x];
+                key.ks = key_ks[r][threadIdx.x];
+                dim = accepted[r][threadIdx.x];
+                jitter_exact(key, dim, dx, dy);
+                dim += 2;
+            }
+            const float px = (float)ux + 0.5f + dx;
+            const float py = (float)uy + 0.5f + dy;
+            const V3 dir = normalize(mk((px - f.cx) / f.fx, (py - f.cy) / f.fy, 1.f));
+            ray = mk(dot(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
+                     dot(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
+                     dot(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
+            w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
+            w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
+        }
+        launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
+    }
 }
 
 // Adds the light contributions a path left pending at its previous hit, in
@@ -1276,7 +1335,10 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t slots = (size_t)n_paths * (1 + nl);
     // a shard receives the rays of every kShards-th wavefront of a path kernel
     const size_t n_waves = (((size_t)n_paths + kBlock - 1) / kBlock) * kWavesPerBlock;
-    const size_t shard_capacity = ((n_waves + kShards - 1) / kShards) * 64 * (1 + nl);
+    // k_shade: a wavefront queues at most 64 * (1 + lights) rays; k_generate: 64 * kGenPaths, from fewer wavefronts
+    const size_t gen_waves = (((size_t)n_paths + kBlock * kGenPaths - 1) / (kBlock * kGenPaths)) * kWavesPerBlock;
+    const size_t shard_capacity = std::max(((n_waves + kShards - 1) / kShards) * 64 * (1 + nl),
+                                           ((gen_waves + kShards - 1) / kShards) * 64 * kGenPaths);
     const size_t queue_entries = shard_capacity * kShards;
     if (queue_entries > 0xffffffffu) { rt_set_error("batch too large for the ray queue"); return RT_ERR_INVALID; }
     // cluster lists: one tile of rays at a time if the whole queue would not fit the budget
@@ -1646,7 +1708,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         if (cull) HIP_TRY(hipMemsetAsync(s->w.cl_count, 0, cl_words * sizeof(uint32_t), stream));
         if (cull && s->d.n_groups)
             HIP_TRY(hipMemsetAsync(s->w.grp_count, 0, (size_t)n_counters * s->tiles * s->d.n_groups * kCountStride * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(k_generate, grid, block, 0, stream, s->d, s->w, f);
+        hipLaunchKernelGGL(k_generate, dim3((f.n_paths + kBlock * kGenPaths - 1) / (kBlock * kGenPaths)), block, 0, stream, s->d, s->w, f);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
             if ((rc = launch_mesh(s, (uint32_t)depth, stream, profile, cull)) != RT_OK) return rc;
