@@ -100,7 +100,7 @@ typedef struct rt_stats {
     uint64_t paths;
     uint64_t mesh_rays;        /* rays that walked the triangle list           */
     uint64_t triangle_tests;   /* ray-triangle tests the triangle kernel executed */
-    uint64_t sphere_casts;     /* casts tested against every sphere            */
+    uint64_t sphere_casts;     /* rays tested against every sphere: camera, bounce and shadow rays */
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* device-resident scene */

@@ -287,6 +287,16 @@ __device__ __forceinline__ void enqueue(const Work& w, uint32_t counter, bool wa
     }
 }
 
+// Statistics: adds the number of lanes with cast == true to word 1 of this
+// wavefront's queue-counter line.  All lanes of the wavefront must call it.
+__device__ __forceinline__ void count_casts(const Work& w, uint32_t counter, bool cast) {
+    const uint32_t n = (uint32_t)__popcll(__ballot(cast));
+    if (n && __lane_id() == 0) {
+        const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
+        atomicAdd(&w.q_count[(counter * kShards + shard) * kCountStride + 1], n);
+    }
+}
+
 // True when the ray has to walk the triangle list (reference
 // src/raytrace.cu:103-146: with boxes enabled only after a box hit).
 __device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, int use_boxes, V3 ray, V3 start) {
@@ -758,6 +768,7 @@ struct Frame {
     uint32_t sample_begin;  // global index of the batch's first sample
     uint32_t seed;
     int32_t indirect, antialiasing, bounding_box, max_depth;
+    int32_t count_casts;    // add the number of rays tested against the spheres to word 1 of the queue counters
 };
 
 __device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return p % f.n_pixels; }
@@ -898,6 +909,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
         }
         launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
+        if (f.count_casts) count_casts(w, 0, alive);
     }
 }
 
@@ -1124,7 +1136,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame 
             }
         }
         enqueue(w, counter, lit && shadow_walk, start, sray, (uint32_t)(f.n_paths + slot), dist);
+        if (f.count_casts) count_casts(w, counter, lit);
     }
+    if (f.count_casts) count_casts(w, counter, alive);
     if (deferred) flags |= F_PENDING;
     if (open) {
         if (!alive) flags &= ~F_ALIVE;
@@ -1390,6 +1404,7 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     f.antialiasing = opt->antialiasing != 0;
     f.bounding_box = opt->bounding_box != 0;
     f.max_depth = opt->max_depth;
+    f.count_casts = 0;
     return f;
 }
 
@@ -1685,6 +1700,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
     if ((rc = ensure_work(s, per_batch * n_pixels, n_counters)) != RT_OK) return rc;
 
     const bool profile = stats && opt->profile;
+    f.count_casts = stats != nullptr;
     const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
     const size_t cl_words = cull ? (size_t)n_counters * s->tiles * s->d.n_clusters * kCountStride : 0;
     std::vector<uint32_t> cl_counts(cl_words);
@@ -1730,7 +1746,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
             if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), s->w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             uint64_t batch_rays = 0;
-            for (size_t i = 0; i < counts.size(); i += kCountStride) batch_rays += counts[i];
+            for (size_t i = 0; i < counts.size(); i += kCountStride) { batch_rays += counts[i]; sphere_casts += counts[i + 1]; }
             mesh_rays += batch_rays;
             if (cull) {
                 for (size_t i = 0; i < cl_words; i += kCountStride) tests += (uint64_t)cl_counts[i] * s->cluster_tris[(i / kCountStride) % s->d.n_clusters];

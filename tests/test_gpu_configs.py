@@ -71,6 +71,24 @@ def test_c3_cat_indirect_aa_bbox_full_size():
     assert st.paths == paths
     # the recorded algorithmic work of this configuration: 7 174 triangle tests per path
     assert st.triangle_tests / paths == pytest.approx(7174, rel=0.02)
+    assert st.sphere_casts / paths == pytest.approx(10.0, rel=0.01)  # recorded: 10 casts per path
+
+
+@pytest.mark.parametrize("scene,mode", [("mesh_scene", (True, True, True)), ("default", (True, True, False)),
+                                        ("simple", (False, True, True))])
+def test_work_counters_equal_the_oracles(scene, mode):
+    """Casts and mesh walks are counted on the device; the oracle counts the same events.  (Not in the
+    mode without indirect light and anti-aliasing: there the reference stops a pixel's sample loop
+    after one sample, src/raytrace.cu:496-498, while the device traces every sample and drops the rest.)"""
+    s = load(scene, 72, 56, 3)
+    desc, cam = s.describe()
+    opt = rt.make_options(*mode, seed=17, cluster_culling=False)
+    img, st = s.upload().render(cam, opt)
+    ref, counters = ob.render_image(desc, cam, ob.from_rt_options(opt))
+    assert same_bits(img, ref)
+    assert st.sphere_casts == counters["casts"]
+    # a handful of mesh walks differ: the oracle also walks for a shadow ray that a sphere already blocks at the same distance
+    assert st.triangle_tests == pytest.approx(counters["triangle_tests"], rel=1e-3)
 
 
 @pytest.mark.parametrize("material", ["glass", "mirror"])
