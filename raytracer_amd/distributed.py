@@ -84,9 +84,9 @@ class FrameRenderer:
             raise ValueError("depth must be at least 1")
         self.slots = [_Slot(torch, self.n_pixels, tensor_device) for _ in range(depth)]
         self.frame = 0
-        on_gpu = str(tensor_device).startswith("cuda")
+        self.on_gpu = str(tensor_device).startswith("cuda")
         # overlap needs a collective that runs on a device stream of its own
-        self.overlap = bool(on_gpu and self.distributed and dist.get_backend(group) == "nccl")
+        self.overlap = bool(self.on_gpu and self.distributed and dist.get_backend(group) == "nccl")
         self.side = torch.cuda.Stream() if self.overlap else None
         # a group of one has nothing to exchange; rehearsals of the stream logic can ask for the collective anyway
         self.exchange = self.world > 1 or (exchange_in_group_of_one and self.distributed)
@@ -138,6 +138,11 @@ class FrameRenderer:
                 slot.done = self.side.record_event()
         else:
             if self.exchange:
+                # host-staged backends (gloo) copy the tensor themselves: hand it over finished.
+                # (Seen on one GPU shared by two gloo ranks: with the accumulate still in flight
+                # the collective stalled for seconds.)
+                if self.on_gpu:
+                    torch.cuda.current_stream().synchronize()
                 self.dist.all_reduce(slot.sum, group=self.group)
             self._resolve(slot.sum, slot.image)
         return slot.image.view(cam.height, cam.width, 3)
