@@ -67,6 +67,7 @@ constexpr uint32_t kShards = 64;            // ray-queue shards = lanes of a wav
 // Every atomically updated counter sits on a 128-byte line of its own: atomics
 // to one line serialise, whatever word of it they touch.
 constexpr uint32_t kCountStride = 32;
+constexpr uint32_t kCastShards = 1024;      // statistics counters per path kernel: one atomic per wavefront, spread over 1024 lines
 constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none)
 constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
 constexpr uint32_t kMaxLights = 64;
@@ -116,6 +117,7 @@ struct Work {
     float4* q_o;     // queued ray origin.xyz, hit slot as uint bits
     float4* q_d;     // queued ray direction.xyz, cut-off distance
     uint32_t* q_count; // kShards counters (kCountStride words apart) per k_mesh stage of a batch
+    uint32_t* cast_count; // statistics: kCastShards counters (kCountStride words apart) per path kernel of a batch
     uint32_t shard_capacity; // queue entries reserved per shard
     // cluster culling: per stage slot, the queue positions of the rays that touch each cluster
     uint32_t* cl_count;      // n_clusters counters per slot
@@ -287,13 +289,13 @@ __device__ __forceinline__ void enqueue(const Work& w, uint32_t counter, bool wa
     }
 }
 
-// Statistics: adds the number of lanes with cast == true to word 1 of this
-// wavefront's queue-counter line.  All lanes of the wavefront must call it.
-__device__ __forceinline__ void count_casts(const Work& w, uint32_t counter, bool cast) {
-    const uint32_t n = (uint32_t)__popcll(__ballot(cast));
+// Statistics: adds n (the wavefront's number of rays tested against the
+// spheres in this kernel) to one of the kernel's counters.  All lanes pass the
+// same n.
+__device__ __forceinline__ void add_casts(const Work& w, uint32_t counter, uint32_t n) {
     if (n && __lane_id() == 0) {
-        const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
-        atomicAdd(&w.q_count[(counter * kShards + shard) * kCountStride + 1], n);
+        const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kCastShards;
+        atomicAdd(&w.cast_count[((size_t)counter * kCastShards + shard) * kCountStride], n);
     }
 }
 
@@ -593,73 +595,102 @@ __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_
 __device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// Slab tests of one ray against box pairs [first, last), last - first <= 16:
-// bit 2(k - first) + h of the result is set when the ray enters box h of pair
-// k before its cut-off distance.  The slab parameters come from packed FMAs
-// (t = bound * (1/u) - origin * (1/u)); this is only a filter and need not
-// follow the reference's rounding.  NaN (inf - inf on an axis-parallel ray) is
-// dropped by the minimum / maximum, which errs towards "touches".
-__device__ __forceinline__ uint32_t slab_bits(const f2* __restrict__ box_pair, uint32_t first, uint32_t last, float ix, float iy, float iz,
-                                              float ox, float oy, float oz, float cutoff) {
-    uint32_t bits = 0;
-    for (uint32_t k = first; k < last; k++) {
-        const f2* __restrict__ b = box_pair + 6 * (size_t)k;
-        const f2 ax = __builtin_elementwise_fma(b[0], (f2)(ix), (f2)(-ox)), bx = __builtin_elementwise_fma(b[3], (f2)(ix), (f2)(-ox));
-        const f2 ay = __builtin_elementwise_fma(b[1], (f2)(iy), (f2)(-oy)), by = __builtin_elementwise_fma(b[4], (f2)(iy), (f2)(-oy));
-        const f2 az = __builtin_elementwise_fma(b[2], (f2)(iz), (f2)(-oz)), bz = __builtin_elementwise_fma(b[5], (f2)(iz), (f2)(-oz));
-        const float in0 = hw_max3(hw_min(ax.x, bx.x), hw_min(ay.x, by.x), hw_min(az.x, bz.x));
-        const float out0 = hw_min3(hw_max(ax.x, bx.x), hw_max(ay.x, by.x), hw_max(az.x, bz.x));
-        const float in1 = hw_max3(hw_min(ax.y, bx.y), hw_min(ay.y, by.y), hw_min(az.y, bz.y));
-        const float out1 = hw_min3(hw_max(ax.y, bx.y), hw_max(ay.y, by.y), hw_max(az.y, bz.y));
-        const bool t0 = (out0 >= hw_max(in0, 0.f)) & (in0 <= cutoff);
-        const bool t1 = (out1 >= hw_max(in1, 0.f)) & (in1 <= cutoff);
-        const uint32_t bit = 1u << (2 * (k - first)); // wave-uniform
-        bits |= (t0 ? bit : 0u) | (t1 ? bit << 1 : 0u);
-    }
-    return bits;
+// One ray prepared for slab tests: 1/u, origin * (1/u), cut-off distance.
+struct SlabRay {
+    float ix, iy, iz, ox, oy, oz, cutoff;
+};
+
+__device__ __forceinline__ SlabRay slab_ray(float4 o4, float4 d4) {
+    SlabRay r;
+    r.ix = 1.f / d4.x; r.iy = 1.f / d4.y; r.iz = 1.f / d4.z; // +-inf for an axis-parallel ray
+    r.ox = o4.x * r.ix; r.oy = o4.y * r.iy; r.oz = o4.z * r.iz;
+    r.cutoff = d4.w;
+    return r;
 }
 
-// Bins one ray per lane (queue position `at`, ignored when !active) against
-// up to 64 padded boxes and appends `at` to the list of every box the ray
-// enters before its cut-off distance.  One pass over the boxes: a lane keeps
-// the boxes its ray touches as a 64-bit mask; then every lane walks the set
-// bits of its mask twice -- to count per box in LDS (`slot`, 64 words), and,
-// after the workgroup has reserved list space with one atomic per box, to
-// take its positions.  All threads of the workgroup must call it.
-__device__ __forceinline__ void bin_rays64(const f2* __restrict__ box_pair, uint32_t n_boxes, bool active, uint32_t at,
+// Slab tests of R rays per lane against box pairs [first, last), last - first
+// <= 16: bit 2(k - first) + h of bits[i] is set when ray i enters box h of
+// pair k before its cut-off distance.  The slab parameters come from packed
+// FMAs (t = bound * (1/u) - origin * (1/u)); this is only a filter and need not
+// follow the reference's rounding.  NaN (inf - inf on an axis-parallel ray) is
+// dropped by the minimum / maximum, which errs towards "touches".  The box
+// data of an iteration (scalar loads) serves all R rays.
+template <int R>
+__device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint32_t first, uint32_t last, const SlabRay (&ray)[R],
+                                          uint32_t (&bits)[R]) {
+#pragma unroll
+    for (int i = 0; i < R; i++) bits[i] = 0;
+    for (uint32_t k = first; k < last; k++) {
+        const f2* __restrict__ b = box_pair + 6 * (size_t)k;
+        const f2 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
+        const uint32_t bit = 1u << (2 * (k - first)); // wave-uniform
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const SlabRay& r = ray[i];
+            const f2 ax = __builtin_elementwise_fma(b0, (f2)(r.ix), (f2)(-r.ox)), bx = __builtin_elementwise_fma(b3, (f2)(r.ix), (f2)(-r.ox));
+            const f2 ay = __builtin_elementwise_fma(b1, (f2)(r.iy), (f2)(-r.oy)), by = __builtin_elementwise_fma(b4, (f2)(r.iy), (f2)(-r.oy));
+            const f2 az = __builtin_elementwise_fma(b2, (f2)(r.iz), (f2)(-r.oz)), bz = __builtin_elementwise_fma(b5, (f2)(r.iz), (f2)(-r.oz));
+            const float in0 = hw_max3(hw_min(ax.x, bx.x), hw_min(ay.x, by.x), hw_min(az.x, bz.x));
+            const float out0 = hw_min3(hw_max(ax.x, bx.x), hw_max(ay.x, by.x), hw_max(az.x, bz.x));
+            const float in1 = hw_max3(hw_min(ax.y, bx.y), hw_min(ay.y, by.y), hw_min(az.y, bz.y));
+            const float out1 = hw_min3(hw_max(ax.y, bx.y), hw_max(ay.y, by.y), hw_max(az.y, bz.y));
+            const bool t0 = (out0 >= hw_max(in0, 0.f)) & (in0 <= r.cutoff);
+            const bool t1 = (out1 >= hw_max(in1, 0.f)) & (in1 <= r.cutoff);
+            bits[i] |= (t0 ? bit : 0u) | (t1 ? bit << 1 : 0u);
+        }
+    }
+}
+
+// Bins R rays per lane (queue positions at[i], ignored when !active[i])
+// against up to 64 padded boxes and appends each position to the list of every
+// box its ray enters before its cut-off distance.  One pass over the boxes: a
+// lane keeps the boxes a ray touches as a 64-bit mask; then every lane walks
+// the set bits of its masks twice -- to count per box in LDS (`slot`, 64
+// words), and, after the workgroup has reserved list space with one atomic per
+// box, to take its positions.  All threads of the workgroup must call it.
+template <int R>
+__device__ __forceinline__ void bin_rays64(const f2* __restrict__ box_pair, uint32_t n_boxes, const bool (&active)[R], const uint32_t (&at)[R],
                                            const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                            uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity,
                                            uint32_t* slot) {
     if (threadIdx.x < 64) slot[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t n_pairs = (n_boxes + 1) / 2;
-    const float4 o4 = q_o[at];
-    const float4 d4 = q_d[at];
-    const float ix = 1.f / d4.x, iy = 1.f / d4.y, iz = 1.f / d4.z; // +-inf for an axis-parallel ray
-    const float ox = o4.x * ix, oy = o4.y * iy, oz = o4.z * iz;
-    // boxes 0-31 and 32-63 this lane's ray touches
-    const uint32_t bits_lo = slab_bits(box_pair, 0, min(n_pairs, 16u), ix, iy, iz, ox, oy, oz, d4.w);
-    const uint32_t bits_hi = n_pairs > 16 ? slab_bits(box_pair, 16, n_pairs, ix, iy, iz, ox, oy, oz, d4.w) : 0u;
+    SlabRay ray[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) ray[i] = slab_ray(q_o[at[i]], q_d[at[i]]);
+    // boxes 0-31 and 32-63 each ray touches
+    uint32_t bits_lo[R], bits_hi[R];
+    slab_bits<R>(box_pair, 0, min(n_pairs, 16u), ray, bits_lo);
+    slab_bits<R>(box_pair, 16, max(n_pairs, 16u), ray, bits_hi);
     // an odd box count leaves the second half of the last entry without a box: drop its bit
     const unsigned long long real = n_boxes >= 64 ? ~0ULL : (1ULL << n_boxes) - 1ULL;
-    const unsigned long long mine = active ? ((((unsigned long long)bits_hi << 32) | bits_lo) & real) : 0ULL;
-    for (unsigned long long m = mine; m; m &= m - 1) atomicAdd(&slot[(uint32_t)__ffsll((long long)m) - 1u], 1u);
+    unsigned long long mine[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        mine[i] = active[i] ? ((((unsigned long long)bits_hi[i] << 32) | bits_lo[i]) & real) : 0ULL;
+        for (unsigned long long m = mine[i]; m; m &= m - 1) atomicAdd(&slot[(uint32_t)__ffsll((long long)m) - 1u], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < n_boxes) {
         const uint32_t total = slot[threadIdx.x];
         slot[threadIdx.x] = total ? atomicAdd(&count[threadIdx.x * kCountStride], total) : 0;
     }
     __syncthreads();
-    for (unsigned long long m = mine; m; m &= m - 1) {
-        const uint32_t c = (uint32_t)__ffsll((long long)m) - 1u;
-        list[(size_t)c * list_capacity + atomicAdd(&slot[c], 1u)] = at;
-    }
+#pragma unroll
+    for (int i = 0; i < R; i++)
+        for (unsigned long long m = mine[i]; m; m &= m - 1) {
+            const uint32_t c = (uint32_t)__ffsll((long long)m) - 1u;
+            list[(size_t)c * list_capacity + atomicAdd(&slot[c], 1u)] = at[i];
+        }
     __syncthreads();
 }
 
 // First level: the queued rays of one tile (256-ray blocks [first_block,
 // first_block + blocks_in_tile)) against the clusters of a mesh of at most 64
-// clusters, or against the groups of a larger one.
+// clusters, or against the groups of a larger one.  A workgroup takes two
+// consecutive ray blocks at a time (two rays per lane), which halves the
+// barriers and reservations per ray.
 __global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ box_pair, uint32_t n_boxes,
                                                   const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                   const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
@@ -668,10 +699,17 @@ __global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ box_pai
     __shared__ uint32_t slot[64];
     const ShardMap map = load_shard_map(q_count);
     const uint32_t end = min(first_block + blocks_in_tile, map.n_ray_blocks);
-    for (uint32_t ray_block = first_block + blockIdx.x; ray_block < end; ray_block += gridDim.x) {
-        bool active;
-        const uint32_t at = ray_position(map, ray_block, shard_capacity, active);
-        bin_rays64(box_pair, n_boxes, active, at, q_o, q_d, count, list, list_capacity, slot);
+    for (uint32_t ray_block = first_block + 2 * blockIdx.x; ray_block < end; ray_block += 2 * gridDim.x) {
+        bool active[2];
+        uint32_t at[2];
+        at[0] = ray_position(map, ray_block, shard_capacity, active[0]);
+        if (ray_block + 1 < end) {
+            at[1] = ray_position(map, ray_block + 1, shard_capacity, active[1]);
+        } else {
+            at[1] = at[0];
+            active[1] = false;
+        }
+        bin_rays64<2>(box_pair, n_boxes, active, at, q_o, q_d, count, list, list_capacity, slot);
     }
 }
 
@@ -692,10 +730,10 @@ __global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl
         const uint32_t g = owner_of_job(first_job, n_groups, job);
         const uint32_t count = grp_count[g * kCountStride];
         const uint32_t e = (job - first_job[g]) * kBlock + threadIdx.x;
-        const bool active = e < count;
-        const uint32_t at = grp_list[(size_t)g * list_capacity + (active ? e : count - 1)];
+        const bool active[1] = {e < count};
+        const uint32_t at[1] = {grp_list[(size_t)g * list_capacity + (active[0] ? e : count - 1)]};
         const uint32_t first_cluster = g * kGroupClusters;
-        bin_rays64(cl_pair + 6 * (size_t)(first_cluster / 2), min(kGroupClusters, n_clusters - first_cluster), active, at, q_o, q_d,
+        bin_rays64<1>(cl_pair + 6 * (size_t)(first_cluster / 2), min(kGroupClusters, n_clusters - first_cluster), active, at, q_o, q_d,
                    cl_count + (size_t)first_cluster * kCountStride, cl_list + (size_t)first_cluster * list_capacity, list_capacity, slot);
     }
 }
@@ -768,7 +806,7 @@ struct Frame {
     uint32_t sample_begin;  // global index of the batch's first sample
     uint32_t seed;
     int32_t indirect, antialiasing, bounding_box, max_depth;
-    int32_t count_casts;    // add the number of rays tested against the spheres to word 1 of the queue counters
+    int32_t count_casts;    // count the rays tested against the spheres (statistics)
 };
 
 __device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return p % f.n_pixels; }
@@ -881,6 +919,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             }
         }
     }
+    uint32_t n_casts = 0;
     for (uint32_t r = 0; r < kGenPaths; r++) {
         const uint32_t p = base + r * kBlock;
         const bool alive = p < f.n_paths;
@@ -909,8 +948,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
         }
         launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
-        if (f.count_casts) count_casts(w, 0, alive);
+        n_casts += (uint32_t)__popcll(__ballot(alive));
     }
+    if (f.count_casts) add_casts(w, 0, n_casts);
 }
 
 // Adds the light contributions a path left pending at its previous hit, in
@@ -966,7 +1006,8 @@ __device__ __forceinline__ V3 reflect(V3 ray, V3 N) { return ray - (2 * dot(ray,
 // the sphere scans and box tests of the shadow rays (diffuse hits) and of the
 // bounce ray.  The first light's shadow ray and the bounce ray of a diffuse
 // hit leave the same point, so their scans run as one (nearest_sphere_pair).
-__global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
+// (At least five wavefronts per SIMD: 96 VGPRs.  One register more would cost a fifth of the occupancy.)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
     __shared__ float4 sphere_lds[kSphereCache];
     const Spheres sp = stage_spheres(sc, sphere_lds);
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
@@ -1136,9 +1177,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, Work w, Frame 
             }
         }
         enqueue(w, counter, lit && shadow_walk, start, sray, (uint32_t)(f.n_paths + slot), dist);
-        if (f.count_casts) count_casts(w, counter, lit);
     }
-    if (f.count_casts) count_casts(w, counter, alive);
+    if (f.count_casts)
+        add_casts(w, counter, (uint32_t)__popcll(__ballot(lit)) * sc.n_lights + (uint32_t)__popcll(__ballot(alive)));
     if (deferred) flags |= F_PENDING;
     if (open) {
         if (!alive) flags &= ~F_ALIVE;
@@ -1375,6 +1416,7 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
         (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
         (rc = work_alloc(s, &s->w.q_o, queue_entries)) || (rc = work_alloc(s, &s->w.q_d, queue_entries)) ||
         (rc = work_alloc(s, &s->w.q_count, (size_t)n_counters * kShards * kCountStride)) ||
+        (rc = work_alloc(s, &s->w.cast_count, (size_t)n_counters * kCastShards * kCountStride)) ||
         (rc = work_alloc(s, &s->w.cl_count, slots_cl * nc * kCountStride)) || (rc = work_alloc(s, &s->w.cl_first, slots_cl * (nc + 1))) ||
         (rc = work_alloc(s, &s->w.cl_list, nc * list_capacity)) ||
         (rc = work_alloc(s, &s->w.grp_count, slots_cl * ng * kCountStride)) || (rc = work_alloc(s, &s->w.grp_first, slots_cl * (ng + 1))) ||
@@ -1712,6 +1754,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         HIP_TRY(hipEventRecord(s->frame_begin, stream));
     }
     std::vector<uint32_t> counts((size_t)n_counters * kShards * kCountStride);
+    std::vector<uint32_t> cast_counts(stats ? (size_t)n_counters * kCastShards * kCountStride : 0);
     uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
     uint32_t batches = 0;
 
@@ -1721,6 +1764,7 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         f.sample_begin = sample_begin + first;
         const dim3 grid((f.n_paths + kBlock - 1) / kBlock), block(kBlock);
         HIP_TRY(hipMemsetAsync(s->w.q_count, 0, counts.size() * sizeof(uint32_t), stream));
+        if (stats) HIP_TRY(hipMemsetAsync(s->w.cast_count, 0, cast_counts.size() * sizeof(uint32_t), stream));
         if (cull) HIP_TRY(hipMemsetAsync(s->w.cl_count, 0, cl_words * sizeof(uint32_t), stream));
         if (cull && s->d.n_groups)
             HIP_TRY(hipMemsetAsync(s->w.grp_count, 0, (size_t)n_counters * s->tiles * s->d.n_groups * kCountStride * sizeof(uint32_t), stream));
@@ -1743,10 +1787,12 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         }
         if (stats) { // the counters are reused by the next batch: read them now
             HIP_TRY(hipMemcpyAsync(counts.data(), s->w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(cast_counts.data(), s->w.cast_count, cast_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), s->w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             uint64_t batch_rays = 0;
-            for (size_t i = 0; i < counts.size(); i += kCountStride) { batch_rays += counts[i]; sphere_casts += counts[i + 1]; }
+            for (size_t i = 0; i < counts.size(); i += kCountStride) batch_rays += counts[i];
+            for (size_t i = 0; i < cast_counts.size(); i += kCountStride) sphere_casts += cast_counts[i];
             mesh_rays += batch_rays;
             if (cull) {
                 for (size_t i = 0; i < cl_words; i += kCountStride) tests += (uint64_t)cl_counts[i] * s->cluster_tris[(i / kCountStride) % s->d.n_clusters];
