@@ -121,10 +121,8 @@ struct Work {
     uint32_t shard_capacity; // queue entries reserved per shard
     // cluster culling: per stage slot, the queue positions of the rays that touch each cluster
     uint32_t* cl_count;      // n_clusters counters per slot
-    uint32_t* cl_first;      // n_clusters + 1 job prefix sums per slot
     uint32_t* cl_list;       // n_clusters lists of list_capacity queue positions (reused by every slot)
     uint32_t* grp_count;     // the same three for the groups of clusters
-    uint32_t* grp_first;
     uint32_t* grp_list;
     uint32_t list_capacity;  // = rays binned per tile
 };
@@ -273,20 +271,23 @@ __device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, V3 ray, V3 st
 // shards with a counter each and a wavefront always uses the shard of its own
 // index, which spreads the returning atomics over 64 addresses (one address
 // serialises at well under 200 atomics per microsecond).
-__device__ __forceinline__ void enqueue(const Work& w, uint32_t counter, bool want, V3 start, V3 ray, uint32_t slot, float cutoff) {
+// Returns the queue position of this lane's ray (0 when want == false).
+__device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, bool want, V3 start, V3 ray, uint32_t slot, float cutoff) {
     const unsigned long long mask = __ballot(want);
-    if (mask == 0) return;
+    if (mask == 0) return 0;
     const uint32_t lane = __lane_id();
     const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
     const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(&w.q_count[(counter * kShards + shard) * kCountStride], (uint32_t)__popcll(mask));
     base = __shfl(base, (int)leader);
+    uint32_t at = 0;
     if (want) {
-        const size_t at = (size_t)shard * w.shard_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
+        at = shard * w.shard_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
         w.q_o[at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot));
         w.q_d[at] = make_float4(ray.x, ray.y, ray.z, cutoff);
     }
+    return at;
 }
 
 // Statistics: adds n (the wavefront's number of rays tested against the
@@ -564,8 +565,8 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
 // (src/raytrace.cu:136-148).  A triangle can only be hit by a ray that passes
 // through the (padded) bounds of the cluster of 64 spatially adjacent
 // triangles it belongs to, before the ray's cut-off distance.  k_bin64 lists,
-// per cluster, the queued rays that do; k_plan turns the list lengths into job
-// offsets; k_mesh_clusters runs the same pair scan as k_mesh over each
+// per cluster, the queued rays that do; k_mesh_clusters turns the list lengths
+// into job offsets (plan_jobs) and runs the same pair scan as k_mesh over each
 // cluster's list.  A mesh of more than 64 clusters gets a second level: groups
 // of 64 consecutive clusters (neighbours in space, the triangles being in
 // Morton order) with the union of their bounds; k_bin64 lists the rays per
@@ -585,6 +586,40 @@ __device__ __forceinline__ uint32_t owner_of_job(const uint32_t* first, uint32_t
         if (first[mid] <= job) lo = mid; else hi = mid - 1;
     }
     return lo;
+}
+
+// first_job[i] = number of 256-entry jobs of the lists before list i,
+// first_job[n] = their total, from the list lengths (count[i * kCountStride]);
+// n <= kMaxClusters.  Every workgroup of a kernel that walks the lists makes
+// its own copy in LDS (`scan` is kBlock words of scratch): the lengths sit in
+// L2 and the scan is a few microseconds, less than a launch of its own would
+// cost.  All threads of the workgroup must call it.
+__device__ __forceinline__ void plan_jobs(const uint32_t* __restrict__ count, uint32_t n, uint32_t* first_job, uint32_t* scan) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n + kBlock - 1) / kBlock; // consecutive lists per thread, at most 16
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = t * per + k;
+        if (i < n) mine += (count[(size_t)i * kCountStride] + kBlock - 1) / kBlock;
+    }
+    scan[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < kBlock; off <<= 1) {
+        const uint32_t v = t >= off ? scan[t - off] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = scan[t] - mine;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = t * per + k;
+        if (i < n) {
+            first_job[i] = run;
+            run += (count[(size_t)i * kCountStride] + kBlock - 1) / kBlock;
+        }
+    }
+    if (t == kBlock - 1) first_job[n] = scan[t];
+    __syncthreads();
 }
 
 // The hardware minimum / maximum: a NaN operand is dropped (minNum / maxNum).
@@ -649,16 +684,12 @@ __device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint3
 // words), and, after the workgroup has reserved list space with one atomic per
 // box, to take its positions.  All threads of the workgroup must call it.
 template <int R>
-__device__ __forceinline__ void bin_rays64(const f2* __restrict__ box_pair, uint32_t n_boxes, const bool (&active)[R], const uint32_t (&at)[R],
-                                           const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                           uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity,
-                                           uint32_t* slot) {
+__device__ __forceinline__ void bin_prepared64(const f2* __restrict__ box_pair, uint32_t n_boxes, const bool (&active)[R], const uint32_t (&at)[R],
+                                               const SlabRay (&ray)[R], uint32_t* __restrict__ count, uint32_t* __restrict__ list,
+                                               uint32_t list_capacity, uint32_t* slot) {
     if (threadIdx.x < 64) slot[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t n_pairs = (n_boxes + 1) / 2;
-    SlabRay ray[R];
-#pragma unroll
-    for (int i = 0; i < R; i++) ray[i] = slab_ray(q_o[at[i]], q_d[at[i]]);
     // boxes 0-31 and 32-63 each ray touches
     uint32_t bits_lo[R], bits_hi[R];
     slab_bits<R>(box_pair, 0, min(n_pairs, 16u), ray, bits_lo);
@@ -686,11 +717,25 @@ __device__ __forceinline__ void bin_rays64(const f2* __restrict__ box_pair, uint
     __syncthreads();
 }
 
+// The same for rays read back from the queue.
+template <int R>
+__device__ __forceinline__ void bin_rays64(const f2* __restrict__ box_pair, uint32_t n_boxes, const bool (&active)[R], const uint32_t (&at)[R],
+                                           const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                           uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity,
+                                           uint32_t* slot) {
+    SlabRay ray[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) ray[i] = slab_ray(q_o[at[i]], q_d[at[i]]);
+    bin_prepared64<R>(box_pair, n_boxes, active, at, ray, count, list, list_capacity, slot);
+}
+
 // First level: the queued rays of one tile (256-ray blocks [first_block,
 // first_block + blocks_in_tile)) against the clusters of a mesh of at most 64
-// clusters, or against the groups of a larger one.  A workgroup takes two
-// consecutive ray blocks at a time (two rays per lane), which halves the
-// barriers and reservations per ray.
+// clusters, or against the groups of a larger one.  A workgroup takes R
+// consecutive ray blocks at a time (R rays per lane): two halve the barriers
+// and reservations per ray, one keeps more workgroups busy when the queue is
+// short.
+template <int R>
 __global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ box_pair, uint32_t n_boxes,
                                                   const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                   const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
@@ -699,32 +744,33 @@ __global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ box_pai
     __shared__ uint32_t slot[64];
     const ShardMap map = load_shard_map(q_count);
     const uint32_t end = min(first_block + blocks_in_tile, map.n_ray_blocks);
-    for (uint32_t ray_block = first_block + 2 * blockIdx.x; ray_block < end; ray_block += 2 * gridDim.x) {
-        bool active[2];
-        uint32_t at[2];
+    for (uint32_t ray_block = first_block + R * blockIdx.x; ray_block < end; ray_block += R * gridDim.x) {
+        bool active[R];
+        uint32_t at[R];
         at[0] = ray_position(map, ray_block, shard_capacity, active[0]);
-        if (ray_block + 1 < end) {
-            at[1] = ray_position(map, ray_block + 1, shard_capacity, active[1]);
-        } else {
-            at[1] = at[0];
-            active[1] = false;
+#pragma unroll
+        for (int i = 1; i < R; i++) {
+            if (ray_block + i < end) {
+                at[i] = ray_position(map, ray_block + i, shard_capacity, active[i]);
+            } else {
+                at[i] = at[0];
+                active[i] = false;
+            }
         }
-        bin_rays64<2>(box_pair, n_boxes, active, at, q_o, q_d, count, list, list_capacity, slot);
+        bin_rays64<R>(box_pair, n_boxes, active, at, q_o, q_d, count, list, list_capacity, slot);
     }
 }
 
 // Second level: the rays on each group's list against the (at most 64)
-// clusters of that group.  A job is 256 list entries of one group; grp_first
-// holds the job prefix sums k_plan made of the group counts.
+// clusters of that group.  A job is 256 list entries of one group.
 __global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl_pair, uint32_t n_clusters, uint32_t n_groups,
                                                        const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                       const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_first,
-                                                       const uint32_t* __restrict__ grp_list,
+                                                       const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_list,
                                                        uint32_t* __restrict__ cl_count, uint32_t* __restrict__ cl_list, uint32_t list_capacity) {
     __shared__ uint32_t slot[64];
     __shared__ uint32_t first_job[64 + 1];
-    if (threadIdx.x <= n_groups) first_job[threadIdx.x] = grp_first[threadIdx.x];
-    __syncthreads();
+    __shared__ uint32_t scan[kBlock];
+    plan_jobs(grp_count, n_groups, first_job, scan);
     const uint32_t n_jobs = first_job[n_groups];
     for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
         const uint32_t g = owner_of_job(first_job, n_groups, job);
@@ -738,43 +784,15 @@ __global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl
     }
 }
 
-// first[i] = number of 256-entry jobs of the lists before i; first[n] = total.  n <= 4096.
-__global__ __launch_bounds__(1024) void k_plan(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ first) {
-    __shared__ uint32_t scan[1024];
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = (n + 1023) / 1024; // consecutive lists per thread, at most 4
-    uint32_t jobs[4] = {0, 0, 0, 0}, mine = 0;
-    for (uint32_t k = 0; k < per; k++) {
-        const uint32_t i = t * per + k;
-        jobs[k] = i < n ? (count[i * kCountStride] + kBlock - 1) / kBlock : 0;
-        mine += jobs[k];
-    }
-    scan[t] = mine;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = t >= off ? scan[t - off] : 0;
-        __syncthreads();
-        scan[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = scan[t] - mine;
-    for (uint32_t k = 0; k < per; k++) {
-        const uint32_t i = t * per + k;
-        if (i < n) first[i] = run;
-        run += jobs[k];
-    }
-    if (t == 1023) first[n] = scan[1023];
-}
-
 __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
                                                           uint32_t n_clusters, uint32_t cluster_pairs,
                                                           const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                          const uint32_t* __restrict__ cl_count, const uint32_t* __restrict__ cl_first,
+                                                          const uint32_t* __restrict__ cl_count,
                                                           const uint32_t* __restrict__ cl_list, uint32_t list_capacity,
                                                           unsigned long long* __restrict__ hit) {
     __shared__ uint32_t first_job[kMaxClusters + 1];
-    for (uint32_t i = threadIdx.x; i <= n_clusters; i += kBlock) first_job[i] = cl_first[i];
-    __syncthreads();
+    __shared__ uint32_t scan[kBlock];
+    plan_jobs(cl_count, n_clusters, first_job, scan);
     const uint32_t n_jobs = first_job[n_clusters];
     const uint32_t n_pairs = (n_tri + 1) / 2;
     for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
@@ -815,14 +833,14 @@ __device__ __forceinline__ uint32_t path_sample(const Frame& f, uint32_t p) { re
 // State write-back of a freshly generated ray whose nearest sphere (ts, sid)
 // and mesh verdict are known, and queueing for k_mesh.  All lanes of the
 // wavefront must call it.
-__device__ __forceinline__ void commit_ray(const Work& w, uint32_t counter, bool alive, uint32_t p, V3 start, V3 ray,
-                                           float ts, int sid, bool walk) {
+__device__ __forceinline__ uint32_t commit_ray(const Work& w, uint32_t counter, bool alive, uint32_t p, V3 start, V3 ray,
+                                               float ts, int sid, bool walk) {
     if (alive) {
         w.ray_o[p] = make_float4(start.x, start.y, start.z, ts);
         w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
         w.hit[p] = kNoHit;
     }
-    enqueue(w, counter, alive && walk, start, ray, p, ts);
+    return enqueue(w, counter, alive && walk, start, ray, p, ts);
 }
 
 // Nearest sphere + box test for a freshly generated ray, then commit_ray.
@@ -854,7 +872,7 @@ __device__ __forceinline__ void launch_ray(const DeviceScene& sc, const Spheres&
 // otherwise the approximate offsets (absolute error far below 1e-4) decide,
 // except within 1e-4 of the half-pixel limit, where the reference's own
 // arithmetic is evaluated.
-constexpr uint32_t kGenPaths = 4;
+constexpr uint32_t kGenPaths = 4; // at most; short batches use fewer so that the grid still fills the chip
 
 __device__ __forceinline__ void jitter_exact(const rt_rng_key& key, uint32_t dim, float& dx, float& dy) {
     const float r1 = rt_rng_uniform(key, dim);
@@ -867,16 +885,17 @@ __device__ __forceinline__ void jitter_exact(const rt_rng_key& key, uint32_t dim
     dy = radius * sn * 1.f;
 }
 
+template <uint32_t kPaths>
 __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f) {
     __shared__ float4 sphere_lds[kSphereCache];
-    __shared__ uint32_t key_kp[kGenPaths][kBlock], key_ks[kGenPaths][kBlock];
-    __shared__ uint32_t accepted[kGenPaths][kBlock]; // first dimension of the accepted draw
+    __shared__ uint32_t key_kp[kPaths][kBlock], key_ks[kPaths][kBlock];
+    __shared__ uint32_t accepted[kPaths][kBlock]; // first dimension of the accepted draw
     const Spheres sp = stage_spheres(sc, sphere_lds);
-    const uint32_t base = blockIdx.x * (kBlock * kGenPaths) + threadIdx.x;
+    const uint32_t base = blockIdx.x * (kBlock * kPaths) + threadIdx.x;
     // only this lane reads what it writes to the three arrays: no barrier needed
     uint32_t owned = 0;
 #pragma unroll
-    for (uint32_t r = 0; r < kGenPaths; r++) {
+    for (uint32_t r = 0; r < kPaths; r++) {
         const uint32_t p = base + r * kBlock;
         if (p < f.n_paths) {
             const rt_rng_key key = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
@@ -920,7 +939,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
         }
     }
     uint32_t n_casts = 0;
-    for (uint32_t r = 0; r < kGenPaths; r++) {
+    for (uint32_t r = 0; r < kPaths; r++) {
         const uint32_t p = base + r * kBlock;
         const bool alive = p < f.n_paths;
         V3 start = mk(f.pos[0], f.pos[1], f.pos[2]);
@@ -1291,6 +1310,7 @@ struct rt_scene {
     uint32_t work_paths = 0;
     uint32_t n_counters = 0;
     uint32_t tiles = 1;                  // cluster-list tiles per k_mesh stage
+    size_t counter_words = 0;            // queue, cluster and group counters: one block starting at w.q_count
     std::vector<uint32_t> cluster_tris;  // triangles per culling cluster
     // profiling events
     std::vector<hipEvent_t> events;   // pool, reused by every call
@@ -1391,9 +1411,11 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     // a shard receives the rays of every kShards-th wavefront of a path kernel
     const size_t n_waves = (((size_t)n_paths + kBlock - 1) / kBlock) * kWavesPerBlock;
     // k_shade: a wavefront queues at most 64 * (1 + lights) rays; k_generate: 64 * kGenPaths, from fewer wavefronts
-    const size_t gen_waves = (((size_t)n_paths + kBlock * kGenPaths - 1) / (kBlock * kGenPaths)) * kWavesPerBlock;
-    const size_t shard_capacity = std::max(((n_waves + kShards - 1) / kShards) * 64 * (1 + nl),
-                                           ((gen_waves + kShards - 1) / kShards) * 64 * kGenPaths);
+    size_t shard_capacity = ((n_waves + kShards - 1) / kShards) * 64 * (1 + nl);
+    for (size_t r = 2; r <= kGenPaths; r *= 2) {
+        const size_t gen_waves = (((size_t)n_paths + kBlock * r - 1) / (kBlock * r)) * kWavesPerBlock;
+        shard_capacity = std::max(shard_capacity, ((gen_waves + kShards - 1) / kShards) * 64 * r);
+    }
     const size_t queue_entries = shard_capacity * kShards;
     if (queue_entries > 0xffffffffu) { rt_set_error("batch too large for the ray queue"); return RT_ERR_INVALID; }
     // cluster lists: one tile of rays at a time if the whole queue would not fit the budget
@@ -1410,20 +1432,23 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
         tiles = (max_blocks + list_capacity / kBlock - 1) / (list_capacity / kBlock);
     }
     const size_t slots_cl = (size_t)n_counters * tiles;
+    const size_t q_words = (size_t)n_counters * kShards * kCountStride;
+    const size_t cl_words = slots_cl * nc * kCountStride, grp_words = slots_cl * ng * kCountStride;
     int rc;
     if ((rc = work_alloc(s, &s->w.ray_o, n_paths)) || (rc = work_alloc(s, &s->w.ray_d, n_paths)) ||
         (rc = work_alloc(s, &s->w.thr, n_paths)) || (rc = work_alloc(s, &s->w.rad, n_paths)) ||
         (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
         (rc = work_alloc(s, &s->w.q_o, queue_entries)) || (rc = work_alloc(s, &s->w.q_d, queue_entries)) ||
-        (rc = work_alloc(s, &s->w.q_count, (size_t)n_counters * kShards * kCountStride)) ||
+        (rc = work_alloc(s, &s->w.q_count, q_words + cl_words + grp_words)) || // one block: cleared with one fill
         (rc = work_alloc(s, &s->w.cast_count, (size_t)n_counters * kCastShards * kCountStride)) ||
-        (rc = work_alloc(s, &s->w.cl_count, slots_cl * nc * kCountStride)) || (rc = work_alloc(s, &s->w.cl_first, slots_cl * (nc + 1))) ||
         (rc = work_alloc(s, &s->w.cl_list, nc * list_capacity)) ||
-        (rc = work_alloc(s, &s->w.grp_count, slots_cl * ng * kCountStride)) || (rc = work_alloc(s, &s->w.grp_first, slots_cl * (ng + 1))) ||
         (rc = work_alloc(s, &s->w.grp_list, ng * list_capacity))) {
         free_work(s);
         return rc;
     }
+    s->w.cl_count = s->w.q_count + q_words;
+    s->w.grp_count = s->w.cl_count + cl_words;
+    s->counter_words = q_words + cl_words + grp_words;
     s->w.shard_capacity = (uint32_t)shard_capacity;
     s->w.list_capacity = (uint32_t)list_capacity;
     s->tiles = (uint32_t)tiles;
@@ -1452,7 +1477,7 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
 
 // One k_mesh stage: the queued rays of `counter` against the mesh, either by
 // the exhaustive scan or through the cluster lists.
-int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile, bool cull) {
+int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile, bool cull, uint32_t batch_paths) {
     if (s->d.n_triangles == 0) return RT_OK;
     // profiling marks: 'B' binning starts, 'M' triangle kernel starts, 'E' it ended
     auto mark = [&](char tag) -> int {
@@ -1475,31 +1500,29 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
         for (uint32_t tile = 0; tile < s->tiles; tile++) {
             const size_t slot = (size_t)counter * s->tiles + tile;
             uint32_t* cl_count = s->w.cl_count + slot * nc * kCountStride;
-            uint32_t* cl_first = s->w.cl_first + slot * (nc + 1);
             if ((rc = mark('B')) != RT_OK) return rc;
             const f2* cl_pair = reinterpret_cast<const f2*>(s->d.cl_pair);
+            // about a third of the paths queue a ray per stage; two ray blocks per workgroup once that fills the grid twice
+            const bool wide = batch_paths >= 6u * 1024u * 1024u;
+            auto bin64 = wide ? k_bin64<2> : k_bin64<1>;
             if (s->d.n_groups == 0) {
-                hipLaunchKernelGGL(k_bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc,
+                hipLaunchKernelGGL(bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
                                    tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list, s->w.list_capacity);
             } else {
                 const uint32_t ng = s->d.n_groups;
                 uint32_t* grp_count = s->w.grp_count + slot * ng * kCountStride;
-                uint32_t* grp_first = s->w.grp_first + slot * (ng + 1);
-                hipLaunchKernelGGL(k_bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
+                hipLaunchKernelGGL(bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
                                    tile * blocks_per_tile, blocks_per_tile, grp_count, s->w.grp_list, s->w.list_capacity);
-                hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)grp_count, ng, grp_first);
                 hipLaunchKernelGGL(k_bin_groups, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc, ng,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)grp_count,
-                                   (const uint32_t*)grp_first, (const uint32_t*)s->w.grp_list, cl_count, s->w.cl_list,
-                                   s->w.list_capacity);
+                                   (const uint32_t*)s->w.grp_list, cl_count, s->w.cl_list, s->w.list_capacity);
             }
-            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cl_count, nc, cl_first);
             if ((rc = mark('M')) != RT_OK) return rc;
             hipLaunchKernelGGL(k_mesh_clusters, dim3(kMeshGrid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
                                s->d.cluster_pairs, (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)cl_count,
-                               (const uint32_t*)cl_first, (const uint32_t*)s->w.cl_list, s->w.list_capacity, s->w.hit);
+                               (const uint32_t*)s->w.cl_list, s->w.list_capacity, s->w.hit);
             if ((rc = mark('E')) != RT_OK) return rc;
         }
     } else {
@@ -1763,19 +1786,22 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
         f.n_paths = in_batch * n_pixels;
         f.sample_begin = sample_begin + first;
         const dim3 grid((f.n_paths + kBlock - 1) / kBlock), block(kBlock);
-        HIP_TRY(hipMemsetAsync(s->w.q_count, 0, counts.size() * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(s->w.q_count, 0, s->counter_words * sizeof(uint32_t), stream));
         if (stats) HIP_TRY(hipMemsetAsync(s->w.cast_count, 0, cast_counts.size() * sizeof(uint32_t), stream));
-        if (cull) HIP_TRY(hipMemsetAsync(s->w.cl_count, 0, cl_words * sizeof(uint32_t), stream));
-        if (cull && s->d.n_groups)
-            HIP_TRY(hipMemsetAsync(s->w.grp_count, 0, (size_t)n_counters * s->tiles * s->d.n_groups * kCountStride * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(k_generate, dim3((f.n_paths + kBlock * kGenPaths - 1) / (kBlock * kGenPaths)), block, 0, stream, s->d, s->w, f);
+        // paths per lane: as many as still leave 2 048 workgroups (8 per CU)
+        if (f.n_paths >= 2048u * kBlock * 4)
+            hipLaunchKernelGGL(k_generate<4>, dim3((f.n_paths + kBlock * 4 - 1) / (kBlock * 4)), block, 0, stream, s->d, s->w, f);
+        else if (f.n_paths >= 2048u * kBlock * 2)
+            hipLaunchKernelGGL(k_generate<2>, dim3((f.n_paths + kBlock * 2 - 1) / (kBlock * 2)), block, 0, stream, s->d, s->w, f);
+        else
+            hipLaunchKernelGGL(k_generate<1>, grid, block, 0, stream, s->d, s->w, f);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
-            if ((rc = launch_mesh(s, (uint32_t)depth, stream, profile, cull)) != RT_OK) return rc;
+            if ((rc = launch_mesh(s, (uint32_t)depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
             hipLaunchKernelGGL(k_shade, grid, block, 0, stream, s->d, s->w, f, depth);
             HIP_TRY(hipGetLastError());
         }
-        if ((rc = launch_mesh(s, (uint32_t)opt->max_depth, stream, profile, cull)) != RT_OK) return rc;
+        if ((rc = launch_mesh(s, (uint32_t)opt->max_depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
         hipLaunchKernelGGL(k_accumulate, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, s->d, s->w, f,
                            reinterpret_cast<float4*>(d_sum));
         HIP_TRY(hipGetLastError());
@@ -1902,7 +1928,7 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
         const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
         if (cull && hipMemset(s->w.cl_count, 0, (size_t)2 * s->tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         if (cull && s->d.n_groups && hipMemset(s->w.grp_count, 0, (size_t)2 * s->tiles * s->d.n_groups * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
-        if (launch_mesh(s, 0, nullptr, false, cull) != RT_OK) { rc = RT_ERR_DEVICE; break; }
+        if (launch_mesh(s, 0, nullptr, false, cull, n) != RT_OK) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, s->w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }
         if (as_segments) {

@@ -34,7 +34,8 @@ def main():
     dev = scene.upload()
     opt = rt.make_options(seed=1)
     out = {}
-    for n in (1, 2, 4, 8):
+    shares = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+    for n in shares:
         for overlapped in (True, False):
             r = FrameRenderer(dev, cam, opt, exchange_in_group_of_one=True)
             r.s_begin, r.s_end = sample_range(0, n, cam.num_rays)
