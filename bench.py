@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--scene", default="mesh_scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exhaustive", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="frames a rank keeps in flight, each on its own stream and scene handle (1 = one after the other)")
     args = ap.parse_args()
 
     import torch
@@ -132,6 +134,8 @@ def main():
     scene.load_scene(os.path.join(rt.ASSETS, "scenes", args.scene + ".json"))
     desc, cam = scene.describe()
     dev = scene.upload()
+    # every frame in flight needs work buffers of its own: further handles of the same scene
+    extra_devs = [scene.upload() for _ in range(max(args.frames_in_flight, 1) - 1)]
     n_pixels = cam.width * cam.height
     spp = cam.num_rays
 
@@ -143,18 +147,21 @@ def main():
     def run(cluster_culling, steps, warmup):
         opt = rt.make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, profile=True,
                               cluster_culling=cluster_culling)
-        renderer = FrameRenderer(dev, cam, opt, want_stats=True)
+        renderer = FrameRenderer(dev, cam, opt, want_stats=True, extra_devs=extra_devs)
         meter = Meter()
         for _ in range(warmup):
             renderer.render()
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
-            # kernel timing events and counter read-back (one stream sync) on every 4th
-            # timed step only; the other steps just enqueue.  With N > 1 the all-reduce and
-            # resolve of a frame overlap the next frame's accumulate (two frames in flight);
-            # the fence below waits for every stream of the device.
-            renderer.want_stats = i % 4 == 0
+            # Steps just enqueue: consecutive frames overlap on the device (two streams), and with
+            # N > 1 so do the all-reduce of one frame and the kernels of the next.  Every 8th step
+            # is a sampling step: the device is drained first, so that the frame runs alone and the
+            # HIP events around its triangle kernels time them undisturbed; its counters are read back.
+            sampling = i % 8 == 0
+            if sampling:
+                torch.cuda.synchronize()
+            renderer.want_stats = sampling
             renderer.last_stats = None
             renderer.render_async()
             meter.add(renderer.last_stats)
@@ -199,6 +206,7 @@ def main():
                 "triangles": int(desc.n_triangles),
                 "mode": "cluster culling on (library default; image bit-identical to the exhaustive scan)",
                 "parallelism": f"spp-split x{world} + RCCL all-reduce of linear radiance" if world > 1 else "single GPU",
+                "frames_in_flight": max(args.frames_in_flight, 1),
             },
             # dominant kernel of the timed region: k_mesh_clusters.  Algorithmic
             # flops of rank 0's launches (47 per ray-triangle test executed)

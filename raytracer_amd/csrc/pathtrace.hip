@@ -1502,8 +1502,8 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
             uint32_t* cl_count = s->w.cl_count + slot * nc * kCountStride;
             if ((rc = mark('B')) != RT_OK) return rc;
             const f2* cl_pair = reinterpret_cast<const f2*>(s->d.cl_pair);
-            // about a third of the paths queue a ray per stage; two ray blocks per workgroup once that fills the grid twice
-            const bool wide = batch_paths >= 6u * 1024u * 1024u;
+            // two ray blocks per workgroup, except for short batches (measured: better from about 2 M paths up)
+            const bool wide = batch_paths >= 1536u * 1024u;
             auto bin64 = wide ? k_bin64<2> : k_bin64<1>;
             if (s->d.n_groups == 0) {
                 hipLaunchKernelGGL(bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc,

@@ -58,16 +58,25 @@ class FrameRenderer:
     logic under the gloo backend.
 
     render() returns a finished-in-stream-order image.  render_async() keeps
-    `depth` frames in flight: with the "nccl" backend the all-reduce and the
-    resolve of frame i run on RCCL's stream and a side stream while the current
-    stream already accumulates frame i + 1, so a sequence of frames costs
-    max(compute, exchange) per frame instead of their sum.  Call wait() (or
-    synchronize the device) before reading images returned by render_async().
+    frames in flight; call wait() (or synchronize the device) before reading the
+    images it returned.  Two arrangements:
+
+    * one scene handle (`dev`): with the "nccl" backend the all-reduce and the
+      resolve of frame i run on RCCL's stream and a side stream while the
+      current stream already accumulates frame i + 1, so a sequence of frames
+      costs max(compute, exchange) per frame instead of their sum;
+    * several handles of the same scene (`extra_devs`: each has its own work
+      buffers): frame i runs entirely -- accumulate, exchange, resolve -- on
+      stream i mod n with handle i mod n, so the kernels of consecutive frames
+      overlap on the device.  Short frames (a rank's share at 8 GPUs is about a
+      million paths) are bound by the start-up and drain of their ~20 kernels;
+      a second frame in flight fills those gaps.
     """
 
     def __init__(self, dev, cam, opt, *, group=None, tensor_device="cuda",
                  accumulate: Optional[Callable] = None, resolve: Optional[Callable] = None,
-                 want_stats: bool = False, depth: int = 2, exchange_in_group_of_one: bool = False):
+                 want_stats: bool = False, depth: int = 2, exchange_in_group_of_one: bool = False,
+                 extra_devs=()):
         import torch
         import torch.distributed as dist
 
@@ -82,18 +91,24 @@ class FrameRenderer:
         self.s_begin, self.s_end = sample_range(self.rank, self.world, cam.num_rays)
         if depth < 1:
             raise ValueError("depth must be at least 1")
-        self.slots = [_Slot(torch, self.n_pixels, tensor_device) for _ in range(depth)]
-        self.frame = 0
         self.on_gpu = str(tensor_device).startswith("cuda")
+        self.devs = [dev, *extra_devs]
+        if len(self.devs) > 1 and not self.on_gpu:
+            raise ValueError("several scene handles need device tensors")
+        # one stream per handle; a slot is only ever used with the handle and stream of its index
+        self.streams = [torch.cuda.Stream() for _ in self.devs] if len(self.devs) > 1 else None
+        self.slots = [_Slot(torch, self.n_pixels, tensor_device) for _ in range(len(self.devs) if self.streams else depth)]
+        self.frame = 0
         # overlap needs a collective that runs on a device stream of its own
         self.overlap = bool(self.on_gpu and self.distributed and dist.get_backend(group) == "nccl")
-        self.side = torch.cuda.Stream() if self.overlap else None
+        self.side = torch.cuda.Stream() if self.overlap and not self.streams else None
         # a group of one has nothing to exchange; rehearsals of the stream logic can ask for the collective anyway
         self.exchange = self.world > 1 or (exchange_in_group_of_one and self.distributed)
         self.want_stats = want_stats
         self.last_stats = None
         self._accumulate = accumulate or self._hip_accumulate
         self._resolve = resolve or self._hip_resolve
+        self._active_dev = dev
 
     # the buffers of the most recent frame (kept for callers that look at them)
     @property
@@ -108,8 +123,8 @@ class FrameRenderer:
         return self.torch.cuda.current_stream().cuda_stream
 
     def _hip_accumulate(self, cam, opt, s_begin, s_end, sum_tensor):
-        self.last_stats = self.dev.accumulate(cam, opt, s_begin, s_end, sum_tensor.data_ptr(), self._stream(),
-                                              want_stats=self.want_stats)
+        self.last_stats = self._active_dev.accumulate(cam, opt, s_begin, s_end, sum_tensor.data_ptr(), self._stream(),
+                                                      want_stats=self.want_stats)
 
     def _hip_resolve(self, sum_tensor, out_tensor):
         import raytracer_amd as rt
@@ -121,8 +136,17 @@ class FrameRenderer:
         torch = self.torch
         cam = cam if cam is not None else self.cam
         opt = opt if opt is not None else self.opt
-        slot = self.slots[self.frame % len(self.slots)]
+        k = self.frame % len(self.slots)
+        slot = self.slots[k]
         self.frame += 1
+        if self.streams:
+            stream = self.streams[k]
+            stream.wait_stream(torch.cuda.current_stream())  # after whatever the caller queued before
+            self._active_dev = self.devs[k]
+            with torch.cuda.stream(stream):
+                self._whole_frame_on_current_stream(slot, cam, opt)
+            self._active_dev = self.dev
+            return slot.image.view(cam.height, cam.width, 3)
         if slot.done is not None:  # the frame that used these buffers `depth` frames ago
             torch.cuda.current_stream().wait_event(slot.done)
             slot.done = None
@@ -137,20 +161,39 @@ class FrameRenderer:
                 self._resolve(slot.sum, slot.image)
                 slot.done = self.side.record_event()
         else:
-            if self.exchange:
-                # host-staged backends (gloo) copy the tensor themselves: hand it over finished.
-                # (Seen on one GPU shared by two gloo ranks: with the accumulate still in flight
-                # the collective stalled for seconds.)
-                if self.on_gpu:
-                    torch.cuda.current_stream().synchronize()
-                self.dist.all_reduce(slot.sum, group=self.group)
+            self._exchange_blocking(slot)
             self._resolve(slot.sum, slot.image)
         return slot.image.view(cam.height, cam.width, 3)
 
+    def _exchange_blocking(self, slot) -> None:
+        if self.exchange:
+            # host-staged backends (gloo) copy the tensor themselves: hand it over finished.
+            # (Seen on one GPU shared by two gloo ranks: with the accumulate still in flight
+            # the collective stalled for seconds.)
+            if self.on_gpu:
+                self.torch.cuda.current_stream().synchronize()
+            self.dist.all_reduce(slot.sum, group=self.group)
+
+    def _whole_frame_on_current_stream(self, slot, cam, opt) -> None:
+        """Stream-ordered after the previous frame of this slot: same stream."""
+        slot.sum.zero_()
+        if self.s_end > self.s_begin:
+            self._accumulate(cam, opt, self.s_begin, self.s_end, slot.sum)
+        if self.exchange and self.overlap:
+            # RCCL's stream waits for this one; wait() then makes this stream (only) wait for RCCL
+            self.dist.all_reduce(slot.sum, group=self.group, async_op=True).wait()
+        else:
+            self._exchange_blocking(slot)
+        self._resolve(slot.sum, slot.image)
+
     def wait(self) -> None:
         """Orders the current stream after every frame enqueued so far."""
-        if self.overlap:
-            self.torch.cuda.current_stream().wait_stream(self.side)
+        current = self.torch.cuda.current_stream() if self.on_gpu else None
+        if self.streams:
+            for stream in self.streams:
+                current.wait_stream(stream)
+        elif self.overlap:
+            current.wait_stream(self.side)
 
     def render(self, cam=None, opt=None):
         """One frame; returns the (H, W, 3) image tensor, ordered on the current stream."""

@@ -376,6 +376,32 @@ def test_frame_renderer_single_rank_matches_render():
     torch.cuda.synchronize()
 
 
+def test_frames_in_flight_on_two_streams():
+    """Two handles of one scene, two streams: consecutive frames overlap on the device and are still
+    the frames a single render call produces."""
+    import torch
+
+    from raytracer_amd.distributed import FrameRenderer
+
+    s = load("mesh_scene", 200, 150, 5)
+    desc, cam = s.describe()
+    dev = s.upload()
+    r = FrameRenderer(dev, cam, rt.make_options(seed=50), extra_devs=[s.upload()])
+    assert len(r.slots) == 2 and r.streams is not None
+    images = [r.render_async(opt=rt.make_options(seed=50 + i)) for i in range(6)]
+    r.wait()
+    torch.cuda.current_stream().synchronize()
+    for i in (4, 5):  # the two slots hold the last two frames
+        want, _ = dev.render(cam, rt.make_options(seed=50 + i))
+        assert np.array_equal(images[i].cpu().numpy().view(np.uint32), want.view(np.uint32)), f"frame {i}"
+    # with statistics: the sampled frame waits for its own stream only
+    r.want_stats = True
+    img = r.render(opt=rt.make_options(seed=77, profile=True)).cpu().numpy()
+    want, _ = dev.render(cam, rt.make_options(seed=77))
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+    assert r.last_stats.paths == 200 * 150 * 5 and r.last_stats.mesh_kernel_launches == 6
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
@@ -422,7 +448,7 @@ def test_two_ranks_on_the_gpu_reproduce_the_single_rank_frame(tmp_path):
     np.testing.assert_allclose(a, ref, rtol=3e-6, atol=1e-4)
 
 
-def _pipelined_worker(rank, world, port, out_dir):
+def _pipelined_worker(rank, world, port, out_dir, rank_mode):
     import torch
     import torch.distributed as dist
 
@@ -436,8 +462,9 @@ def _pipelined_worker(rank, world, port, out_dir):
         s = load("mesh_scene", 160, 120, 5)
         desc, cam = s.describe()
         dev = s.upload()
-        r = FrameRenderer(dev, cam, rt.make_options(seed=40), exchange_in_group_of_one=True)
-        assert r.overlap and r.exchange
+        extra = [s.upload()] if rank_mode == "two handles" else []
+        r = FrameRenderer(dev, cam, rt.make_options(seed=40), exchange_in_group_of_one=True, extra_devs=extra)
+        assert r.overlap and r.exchange and (r.streams is not None) == bool(extra)
         # seven frames with their own seeds through two slots, nothing waited for in between
         images = [r.render_async(opt=rt.make_options(seed=40 + i)) for i in range(7)]
         last_two = [images[5].clone(), images[6].clone()]  # clone is ordered on the current stream: too early on purpose
@@ -451,12 +478,13 @@ def _pipelined_worker(rank, world, port, out_dir):
         want, _ = dev.render(cam, rt.make_options(seed=99))
         assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
         del last_two
-        np.save(os.path.join(out_dir, "ok.npy"), np.ones(1))
+        np.save(os.path.join(out_dir, f"ok_{rank_mode.replace(' ', '_')}.npy"), np.ones(1))
     finally:
         dist.destroy_process_group()
 
 
-def test_pipelined_frames_over_rccl_group_of_one(tmp_path):
+@pytest.mark.parametrize("mode", ["side stream", "two handles"])
+def test_pipelined_frames_over_rccl_group_of_one(tmp_path, mode):
     """Stream logic of the overlapped path (RCCL collective on its own stream, resolve on a side
     stream, buffer reuse after two frames), rehearsed on the one GPU of the test box."""
     import socket
@@ -466,5 +494,5 @@ def test_pipelined_frames_over_rccl_group_of_one(tmp_path):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    mp.start_processes(_pipelined_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
-    assert os.path.exists(tmp_path / "ok.npy")
+    mp.start_processes(_pipelined_worker, args=(1, port, str(tmp_path), mode), nprocs=1, join=True, start_method="spawn")
+    assert os.path.exists(tmp_path / f"ok_{mode.replace(' ', '_')}.npy")

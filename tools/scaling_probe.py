@@ -36,8 +36,9 @@ def main():
     out = {}
     shares = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
     for n in shares:
-        for overlapped in (True, False):
-            r = FrameRenderer(dev, cam, opt, exchange_in_group_of_one=True)
+        for overlapped in ("three handles", "two handles", True, False):
+            extra = [scene.upload() for _ in range({"three handles": 2, "two handles": 1}.get(overlapped, 0))]
+            r = FrameRenderer(dev, cam, opt, exchange_in_group_of_one=True, extra_devs=extra)
             r.s_begin, r.s_end = sample_range(0, n, cam.num_rays)
             step = r.render_async if overlapped else r.render
             for _ in range(5):
@@ -49,8 +50,9 @@ def main():
                 step()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / frames * 1e3
-            out[f"share_1_of_{n}_{'overlapped' if overlapped else 'serial'}_ms"] = ms
-            print(f"share 1/{n} ({r.s_end - r.s_begin} spp) {'overlapped' if overlapped else 'serial    '}: {ms:.3f} ms/frame", flush=True)
+            label = overlapped if isinstance(overlapped, str) else ("overlapped" if overlapped else "serial")
+            out[f"share_1_of_{n}_{label.replace(' ', '_')}_ms"] = ms
+            print(f"share 1/{n} ({r.s_end - r.s_begin} spp) {label:11s}: {ms:.3f} ms/frame", flush=True)
     print(json.dumps(out))
     dist.destroy_process_group()
 
