@@ -59,3 +59,54 @@ def test_random_scene_matches_the_oracle(seed, tmp_path):
             img, _ = dev.render(cam, rt.make_options(*flags, seed=seed, cluster_culling=culling))
             assert same_bits(img, ref), (f"seed {seed} mode {mode} culling {culling}: {(img != ref).any(axis=2).sum()} pixels differ, "
                                          f"{desc.n_triangles} triangles, {desc.n_spheres} spheres, {desc.n_lights} lights")
+
+
+def test_more_spheres_than_the_lds_cache_holds(tmp_path):
+    """100 spheres: the first 64 are read from LDS, the rest from global memory."""
+    rng = np.random.default_rng(99)
+    s = random_scene(3, tmp_path)
+    for _ in range(95):
+        s.add_sphere(rng.uniform(-30, 30, 3), float(rng.uniform(0.5, 3)), rng.uniform(0.1, 1.0, 3), int(rng.integers(0, 3)), 1.0, 1.5)
+    desc, cam = s.describe()
+    assert desc.n_spheres > 100
+    opt = rt.make_options(seed=5)
+    img, _ = s.upload().render(cam, opt)
+    ref, _ = ob.render_image(desc, cam, ob.from_rt_options(opt))
+    assert same_bits(img, ref)
+
+
+def test_twelve_lights_with_meshes(tmp_path):
+    """Every light's shadow ray may have to wait for the triangle kernel: twelve pending slots per hit."""
+    rng = np.random.default_rng(7)
+    s = random_scene(1, tmp_path)  # seed 1 has meshes
+    for _ in range(10):
+        s.add_light(rng.uniform(-30, 30, 3), float(rng.uniform(5e8, 3e9)))
+    desc, cam = s.describe()
+    assert desc.n_lights >= 11 and desc.n_triangles > 0
+    dev = s.upload()
+    for flags in (MODES["indirect_aa_bbox"], MODES["aa_bbox"]):
+        ref, _ = ob.render_image(desc, cam, ob.options(*flags, seed=9))
+        for culling in (True, False):
+            img, _ = dev.render(cam, rt.make_options(*flags, seed=9, cluster_culling=culling))
+            assert same_bits(img, ref)
+
+
+def test_degenerate_triangles(tmp_path):
+    """Zero-area and repeated-vertex faces have N = 0: the denominator u.N is zero and the
+    reference's comparisons reject the NaN / inf results; so must both triangle kernels."""
+    p = tmp_path / "degenerate.obj"
+    p.write_text("v -6 -6 0\nv 6 -6 0\nv 0 7 0\nv 0 7 0\nv 3 0.5 0\nv 12 2 -3\nvn 0 0 1\n"
+                 "f 1//1 2//1 3//1\nf 1//1 1//1 2//1\nf 1//1 5//1 3//1\nf 3//1 4//1 6//1\nf 2//1 6//1 3//1\n")
+    s = rt.Scene()
+    s.load_scene(os.path.join(rt.ASSETS, "scenes", "simple.json"))
+    s.set_camera_intrinsics(60.0, 72, 60)
+    s.set_num_rays(3)
+    s.add_object(str(p), [0, 0, 15], [1, 1, 1], [0, 20, 0], [0.8, 0.8, 0.2], rt.DIFFUSE)
+    desc, cam = s.describe()
+    assert desc.n_triangles == 5
+    dev = s.upload()
+    for bbox in (True, False):
+        ref, _ = ob.render_image(desc, cam, ob.options(bounding_box=bbox, seed=2))
+        for culling in (True, False):
+            img, _ = dev.render(cam, rt.make_options(bounding_box=bbox, seed=2, cluster_culling=culling))
+            assert same_bits(img, ref)
