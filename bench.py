@@ -51,6 +51,10 @@ def cpu_baseline(desc, cam, opt, n_pixels_sample=65536):
     t0 = time.perf_counter()
     _, _, _, counters = ob.render_pixels(desc, cam, oopt, pixels, threads=threads)
     dt = time.perf_counter() - t0
+    # the same on one thread, on a sixteenth of the sample
+    t1 = time.perf_counter()
+    _, _, _, single = ob.render_pixels(desc, cam, oopt, pixels[: max(n_pixels_sample // 16, 1)], threads=1)
+    dt1 = time.perf_counter() - t1
     return {
         "value": counters["paths"] / dt / 1e6,
         "unit": "Mpaths/s",
@@ -59,6 +63,8 @@ def cpu_baseline(desc, cam, opt, n_pixels_sample=65536):
         "sample": f"{n_pixels_sample} random pixels x {cam.num_rays} spp of the same frame "
                   f"({counters['paths']} paths, {dt:.1f} s, {counters['triangle_tests'] / counters['paths']:.0f} "
                   f"triangle tests/path)",
+        "single_thread_value": single["paths"] / dt1 / 1e6,
+        "single_thread_sample": f"{single['paths']} paths, {dt1:.1f} s",
     }
 
 

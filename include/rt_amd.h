@@ -134,6 +134,12 @@ int rt_accumulate(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
                   uint32_t sample_begin, uint32_t sample_end, float* d_sum,
                   void* stream, rt_stats* stats);
 int rt_resolve(const float* d_sum, uint32_t n_pixels, float* d_out_rgb, void* stream);
+/* The same for the image rows [row_begin, row_end) only (d_sum still covers
+ * the whole image; the other rows are left alone): lets more devices than
+ * there are samples per pixel share a frame as row bands x sample ranges. */
+int rt_accumulate_rows(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
+                       uint32_t sample_begin, uint32_t sample_end, uint32_t row_begin,
+                       uint32_t row_end, float* d_sum, void* stream, rt_stats* stats);
 
 /* Replaces the reference's progress bar (src/raytrace.cu:601-627, a mapped
  * counter the host polls while the kernel runs).  A frame is rendered in

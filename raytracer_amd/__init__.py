@@ -122,6 +122,8 @@ def _load() -> C.CDLL:
         "rt_scene_free": [vp],
         "rt_render": [vp, C.POINTER(Camera), C.POINTER(Options), _f32p, C.POINTER(Stats)],
         "rt_accumulate": [vp, C.POINTER(Camera), C.POINTER(Options), C.c_uint32, C.c_uint32, vp, vp, C.POINTER(Stats)],
+        "rt_accumulate_rows": [vp, C.POINTER(Camera), C.POINTER(Options), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp,
+                               C.POINTER(Stats)],
         "rt_resolve": [vp, C.c_uint32, vp, vp],
         "rt_cast": [vp, C.POINTER(Options), C.c_uint32, _f32p, _f32p, _f32p, _i32p, _i32p, _f32p],
         "rt_visible": [vp, C.POINTER(Options), C.c_uint32, _f32p, _f32p, _i32p],
@@ -164,7 +166,7 @@ EXPORTS = [
     "rt_host_scene_set_camera_intrinsics", "rt_host_scene_rotate_camera", "rt_host_scene_transform_camera",
     "rt_host_scene_set_num_rays", "rt_host_scene_add_sphere", "rt_host_scene_add_object", "rt_host_scene_add_light",
     "rt_host_scene_set_options", "rt_host_scene_render", "rt_host_scene_describe", "rt_host_scene_image",
-    "rt_write_png", "rt_write_pfm", "rt_set_progress", "rt_host_scene_render_frames",
+    "rt_write_png", "rt_write_pfm", "rt_set_progress", "rt_host_scene_render_frames", "rt_accumulate_rows",
 ]
 
 
@@ -270,10 +272,12 @@ class DeviceScene:
         return out, st
 
     def accumulate(self, cam: Camera, opt: Options, sample_begin: int, sample_end: int, d_sum_ptr: int,
-                   stream: int = 0, want_stats: bool = False) -> Optional[Stats]:
+                   stream: int = 0, want_stats: bool = False, rows: Optional[Tuple[int, int]] = None) -> Optional[Stats]:
+        """Adds samples [sample_begin, sample_end) of the image rows `rows` (default: all) to the device buffer."""
         st = Stats() if want_stats else None
-        _check(lib.rt_accumulate(self._h, C.byref(cam), C.byref(opt), sample_begin, sample_end, C.c_void_p(d_sum_ptr),
-                                 C.c_void_p(stream), C.byref(st) if st is not None else None))
+        row_begin, row_end = rows if rows is not None else (0, cam.height)
+        _check(lib.rt_accumulate_rows(self._h, C.byref(cam), C.byref(opt), sample_begin, sample_end, row_begin, row_end,
+                                      C.c_void_p(d_sum_ptr), C.c_void_p(stream), C.byref(st) if st is not None else None))
         return st
 
     def set_progress(self, callback) -> None:

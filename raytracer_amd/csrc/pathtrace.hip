@@ -819,7 +819,8 @@ struct Frame {
     float rot[9];
     float pos[3];
     float fx, fy, cx, cy;
-    uint32_t width, n_pixels;
+    uint32_t width, n_pixels; // n_pixels = pixels rendered: the whole image, or a band of its rows
+    uint32_t pixel_offset;  // index of the band's first pixel in the image
     uint32_t n_paths;       // paths in this batch = n_pixels * samples in batch
     uint32_t sample_begin;  // global index of the batch's first sample
     uint32_t seed;
@@ -827,7 +828,7 @@ struct Frame {
     int32_t count_casts;    // count the rays tested against the spheres (statistics)
 };
 
-__device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return p % f.n_pixels; }
+__device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return f.pixel_offset + p % f.n_pixels; }
 __device__ __forceinline__ uint32_t path_sample(const Frame& f, uint32_t p) { return f.sample_begin + p / f.n_pixels; }
 
 // State write-back of a freshly generated ray whose nearest sphere (ts, sid)
@@ -1217,7 +1218,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
 __global__ __launch_bounds__(kBlock) void k_accumulate(DeviceScene sc, Work w, Frame f, float4* __restrict__ sum) {
     const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
     if (pixel >= f.n_pixels) return;
-    float4 acc = sum[pixel];
+    float4 acc = sum[f.pixel_offset + pixel];
     const uint32_t n_samples = f.n_paths / f.n_pixels;
     for (uint32_t s = 0; s < n_samples; s++) {
         const uint32_t p = s * f.n_pixels + pixel;
@@ -1231,7 +1232,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DeviceScene sc, Work w, F
         acc.w += 1.f;
         if (!f.indirect && (flags & F_EARLY)) break;
     }
-    sum[pixel] = acc;
+    sum[f.pixel_offset + pixel] = acc;
 }
 
 // gamma((1/actual_rays) * colour) (reference src/raytrace.cu:44-51,500)
@@ -1464,6 +1465,7 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     f.fx = cam->fx; f.fy = cam->fy; f.cx = cam->cx; f.cy = cam->cy;
     f.width = cam->width;
     f.n_pixels = cam->width * cam->height;
+    f.pixel_offset = 0;
     f.n_paths = 0;
     f.sample_begin = 0;
     f.seed = opt->seed;
@@ -1748,11 +1750,22 @@ extern "C" int rt_set_progress(rt_scene* s, rt_progress_fn fn, void* user) {
 
 extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin,
                              uint32_t sample_end, float* d_sum, void* stream_, rt_stats* stats) {
+    return rt_accumulate_rows(s, cam, opt, sample_begin, sample_end, 0, cam ? cam->height : 0, d_sum, stream_, stats);
+}
+
+extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin,
+                                  uint32_t sample_end, uint32_t row_begin, uint32_t row_end, float* d_sum, void* stream_,
+                                  rt_stats* stats) {
     int rc = check_frame(s, cam, opt);
     if (rc != RT_OK) return rc;
     if (!d_sum || sample_end < sample_begin) { rt_set_error("rt_accumulate: bad sample range or null buffer"); return RT_ERR_INVALID; }
+    if (row_end < row_begin || row_end > cam->height) { rt_set_error("rt_accumulate_rows: rows [%u, %u) of %u", row_begin, row_end, cam->height); return RT_ERR_INVALID; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Frame f = make_frame(cam, opt);
+    f.n_pixels = (row_end - row_begin) * cam->width;
+    f.pixel_offset = row_begin * cam->width;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (f.n_pixels == 0) return RT_OK;
     const uint32_t n_pixels = f.n_pixels;
     const uint32_t n_samples = sample_end - sample_begin;
     if (stats) std::memset(stats, 0, sizeof *stats);

@@ -27,6 +27,22 @@ def sample_range(rank: int, world: int, spp: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def frame_partition(rank: int, world: int, spp: int, height: int) -> Tuple[int, int, int, int]:
+    """(sample_begin, sample_end, row_begin, row_end) of one frame for `rank` of `world`.
+
+    Samples are split first (perfectly balanced, every rank sees all pixels).  Only when there are
+    more ranks than samples per pixel is the image also cut into bands of rows: the ranks form
+    S sample groups x B bands with S the largest divisor of `world` not above spp.
+    """
+    if world <= 0 or not 0 <= rank < world or spp < 0 or height < 0:
+        raise ValueError(f"bad partition request rank={rank} world={world} spp={spp} height={height}")
+    groups = max(d for d in range(1, world + 1) if world % d == 0 and d <= max(spp, 1))
+    bands = world // groups
+    s_begin, s_end = sample_range(rank % groups, groups, spp)
+    r_begin, r_end = sample_range(rank // groups, bands, height)
+    return s_begin, s_end, r_begin, r_end
+
+
 def frame_share(rank: int, world: int) -> Tuple[int, int]:
     """(first, stride) for Scene.render_frames: rank r of N draws frames r, r + N, r + 2N, ...
 
@@ -50,9 +66,10 @@ class _Slot:
 class FrameRenderer:
     """Renders whole frames of one scene with the samples split over a process group.
 
-    accumulate(cam, opt, s_begin, s_end, sum_tensor) must ADD the linear colour
-    sums and sample counts of the sample range into sum_tensor (4 floats per
-    pixel); resolve(sum_tensor, out_tensor) must write gamma(mean).  The
+    accumulate(cam, opt, s_begin, s_end, sum_tensor, rows) must ADD the linear
+    colour sums and sample counts of the sample range, for the image rows
+    rows = (begin, end), into sum_tensor (4 floats per pixel of the whole
+    image); resolve(sum_tensor, out_tensor) must write gamma(mean).  The
     defaults call the HIP library on the current CUDA stream; the CPU test
     suite injects host implementations to exercise the partition + reduction
     logic under the gloo backend.
@@ -88,7 +105,7 @@ class FrameRenderer:
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.n_pixels = cam.width * cam.height
-        self.s_begin, self.s_end = sample_range(self.rank, self.world, cam.num_rays)
+        self.s_begin, self.s_end, self.row_begin, self.row_end = frame_partition(self.rank, self.world, cam.num_rays, cam.height)
         if depth < 1:
             raise ValueError("depth must be at least 1")
         self.on_gpu = str(tensor_device).startswith("cuda")
@@ -122,9 +139,9 @@ class FrameRenderer:
     def _stream(self) -> int:
         return self.torch.cuda.current_stream().cuda_stream
 
-    def _hip_accumulate(self, cam, opt, s_begin, s_end, sum_tensor):
+    def _hip_accumulate(self, cam, opt, s_begin, s_end, sum_tensor, rows):
         self.last_stats = self._active_dev.accumulate(cam, opt, s_begin, s_end, sum_tensor.data_ptr(), self._stream(),
-                                                      want_stats=self.want_stats)
+                                                      want_stats=self.want_stats, rows=rows)
 
     def _hip_resolve(self, sum_tensor, out_tensor):
         import raytracer_amd as rt
@@ -151,8 +168,8 @@ class FrameRenderer:
             torch.cuda.current_stream().wait_event(slot.done)
             slot.done = None
         slot.sum.zero_()
-        if self.s_end > self.s_begin:
-            self._accumulate(cam, opt, self.s_begin, self.s_end, slot.sum)
+        if self.s_end > self.s_begin and self.row_end > self.row_begin:
+            self._accumulate(cam, opt, self.s_begin, self.s_end, slot.sum, (self.row_begin, self.row_end))
         if self.exchange and self.overlap:
             # the collective is ordered after the accumulate; the current stream does not wait for it
             work = self.dist.all_reduce(slot.sum, group=self.group, async_op=True)
@@ -177,8 +194,8 @@ class FrameRenderer:
     def _whole_frame_on_current_stream(self, slot, cam, opt) -> None:
         """Stream-ordered after the previous frame of this slot: same stream."""
         slot.sum.zero_()
-        if self.s_end > self.s_begin:
-            self._accumulate(cam, opt, self.s_begin, self.s_end, slot.sum)
+        if self.s_end > self.s_begin and self.row_end > self.row_begin:
+            self._accumulate(cam, opt, self.s_begin, self.s_end, slot.sum, (self.row_begin, self.row_end))
         if self.exchange and self.overlap:
             # RCCL's stream waits for this one; wait() then makes this stream (only) wait for RCCL
             self.dist.all_reduce(slot.sum, group=self.group, async_op=True).wait()

@@ -18,7 +18,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from raytracer_amd.distributed import FrameRenderer, sample_range  # noqa: E402
+from raytracer_amd.distributed import FrameRenderer, frame_partition, sample_range  # noqa: E402
 
 
 def test_sample_range_partitions_exactly():
@@ -38,16 +38,32 @@ def test_sample_range_partitions_exactly():
         sample_range(2, 2, 8)
 
 
+def test_frame_partition_covers_every_sample_of_every_row_once():
+    for spp in (1, 2, 3, 4, 32):
+        for world in (1, 2, 3, 4, 6, 8):
+            for height in (1, 5, 16):
+                seen = np.zeros((height, spp), np.int32)
+                for r in range(world):
+                    sb, se, rb, re = frame_partition(r, world, spp, height)
+                    seen[rb:re, sb:se] += 1
+                assert (seen == 1).all(), (spp, world, height)
+    # more samples than ranks: no bands
+    assert [frame_partition(r, 4, 32, 512) for r in range(4)] == [(8 * r, 8 * r + 8, 0, 512) for r in range(4)]
+    # 8 ranks, 4 samples: 4 sample groups x 2 bands
+    assert frame_partition(5, 8, 4, 512) == (1, 2, 256, 512)
+    with pytest.raises(ValueError):
+        frame_partition(3, 3, 4, 16)
+
+
 def _host_callbacks(desc, n_pixels):
     import oracle_binding as ob
 
-    pixels = np.arange(n_pixels, dtype=np.uint32)
-
-    def accumulate(cam, opt, s_begin, s_end, sum_tensor):
+    def accumulate(cam, opt, s_begin, s_end, sum_tensor, rows):
+        pixels = np.arange(rows[0] * cam.width, rows[1] * cam.width, dtype=np.uint32)
         _, ssum, count, _ = ob.render_pixels(desc, cam, ob.from_rt_options(opt), pixels, s_begin, s_end, threads=2)
         buf = sum_tensor.view(n_pixels, 4).numpy()
-        buf[:, :3] += ssum
-        buf[:, 3] += count
+        buf[pixels, :3] += ssum
+        buf[pixels, 3] += count
 
     def resolve(sum_tensor, out_tensor):
         buf = sum_tensor.view(n_pixels, 4).numpy()
@@ -75,6 +91,7 @@ def _worker(rank, world, port, spp, out_dir):
         assert torch.equal(first, second)
         np.save(os.path.join(out_dir, f"img{rank}.npy"), first.numpy())
         np.save(os.path.join(out_dir, f"range{rank}.npy"), np.array([r.s_begin, r.s_end]))
+        np.save(os.path.join(out_dir, f"rows{rank}.npy"), np.array([r.row_begin, r.row_end]))
     finally:
         dist.destroy_process_group()
 
@@ -99,9 +116,32 @@ def test_two_ranks_reproduce_the_single_rank_frame(tmp_path, spp):
     ref, _ = ob.render_image(desc, cam, ob.from_rt_options(rt.make_options(seed=21)))
     imgs = [np.load(tmp_path / f"img{r}.npy") for r in range(world)]
     ranges = [tuple(np.load(tmp_path / f"range{r}.npy")) for r in range(world)]
-    assert ranges == [sample_range(r, world, spp) for r in range(world)]
+    rows = [tuple(np.load(tmp_path / f"rows{r}.npy")) for r in range(world)]
+    assert [ranges[r] + rows[r] for r in range(world)] == [frame_partition(r, world, spp, 16) for r in range(world)]
     assert np.array_equal(imgs[0], imgs[1])  # every rank ends with the same image
     # the split changes only the order of a few fp32 additions
     np.testing.assert_allclose(imgs[0], ref, rtol=2e-6, atol=1e-4)
-    if spp == 1:  # rank 1 had nothing to render: the sum is rank 0's alone, bit for bit
+    if spp == 1:  # one sample: the ranks took the two halves of the rows, every pixel's sum is one rank's
+        assert rows == [(0, 8), (8, 16)]
         assert np.array_equal(imgs[0].view(np.uint32), ref.view(np.uint32))
+
+
+
+def test_three_ranks_two_samples_use_row_bands(tmp_path):
+    """More ranks than samples per pixel: 1 sample group x 3 bands of rows (3 has no divisor <= 2 but 1)."""
+    world, spp = 3, 2
+    mp.spawn(_worker, args=(world, _free_port(), spp, str(tmp_path)), nprocs=world, join=True)
+
+    import oracle_binding as ob
+    import raytracer_amd as rt
+    from helpers import load
+
+    s = load("default", 24, 16, spp)
+    desc, cam = s.describe()
+    ref, _ = ob.render_image(desc, cam, ob.from_rt_options(rt.make_options(seed=21)))
+    rows = [tuple(np.load(tmp_path / f"rows{r}.npy")) for r in range(world)]
+    assert rows == [(0, 6), (6, 11), (11, 16)]
+    imgs = [np.load(tmp_path / f"img{r}.npy") for r in range(world)]
+    assert all(np.array_equal(imgs[0], i) for i in imgs[1:])
+    # every pixel's samples were added by one rank, in order: bit-identical to the single-rank frame
+    assert np.array_equal(imgs[0].view(np.uint32), ref.view(np.uint32))

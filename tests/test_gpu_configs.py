@@ -376,6 +376,33 @@ def test_frame_renderer_single_rank_matches_render():
     torch.cuda.synchronize()
 
 
+def test_row_bands_and_sample_ranges_tile_a_frame():
+    """rt_accumulate_rows: 2 sample groups x 3 bands of rows add up to the frame rt_render draws, bit for bit
+    inside a sample group and to fp32 addition order across the two."""
+    from hip_mem import DeviceBuffer
+
+    from raytracer_amd.distributed import frame_partition
+
+    s = load("mesh_scene", 96, 70, 4)
+    desc, cam = s.describe()
+    dev = s.upload()
+    opt = rt.make_options(seed=23)
+    n = cam.width * cam.height
+    buf, out = DeviceBuffer(4 * n), DeviceBuffer(3 * n)
+    for rank in range(6):
+        sb, se, rb, re = frame_partition(rank, 6, 2, cam.height)  # pretend spp = 2 groups: (0,1), (1,2)
+        dev.accumulate(cam, opt, 2 * sb, 2 * se, buf.address, rows=(rb, re))
+    whole = DeviceBuffer(4 * n)
+    dev.accumulate(cam, opt, 0, 4, whole.address)
+    assert np.array_equal(buf.to_host().view(np.uint32), whole.to_host().view(np.uint32))
+    rt.resolve(buf.address, n, out.address)
+    img, _ = dev.render(cam, opt)
+    assert np.array_equal(out.to_host().view(np.uint32), img.ravel().view(np.uint32))
+    with pytest.raises(rt.RtError):
+        dev.accumulate(cam, opt, 0, 1, buf.address, rows=(3, cam.height + 1))
+    dev.accumulate(cam, opt, 0, 1, buf.address, rows=(5, 5))  # empty band: nothing to do
+
+
 def test_frames_in_flight_on_two_streams():
     """Two handles of one scene, two streams: consecutive frames overlap on the device and are still
     the frames a single render call produces."""

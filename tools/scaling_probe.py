@@ -39,7 +39,7 @@ def main():
         for overlapped in ("three handles", "two handles", True, False):
             extra = [scene.upload() for _ in range({"three handles": 2, "two handles": 1}.get(overlapped, 0))]
             r = FrameRenderer(dev, cam, opt, exchange_in_group_of_one=True, extra_devs=extra)
-            r.s_begin, r.s_end = sample_range(0, n, cam.num_rays)
+            r.s_begin, r.s_end = sample_range(0, n, cam.num_rays)  # rank 0's share of an n-rank run; all rows
             step = r.render_async if overlapped else r.render
             for _ in range(5):
                 step()
