@@ -178,6 +178,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), meter, opt
 
+    # set-up, not a step: one frame per handle so that the work buffers exist whatever --warmup is
+    for handle in [dev, *extra_devs]:
+        FrameRenderer(handle, cam, rt.make_options(seed=1), depth=1).render()
+    fence()
+
     elapsed, meter, opt = run(True, args.steps, args.warmup)
     exhaustive = None
     if not args.no_exhaustive:
