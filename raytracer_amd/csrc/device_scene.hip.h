@@ -1,0 +1,290 @@
+// device_scene.hip.h -- constants, the scene and work-buffer layouts in HBM, vector arithmetic in the reference's operation order, sphere and box intersection, the ray queue.
+// Part of the device half of librt_amd.so; included by pathtrace.hip only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/rt_amd.h"
+#include "rt_math.h"
+
+namespace {
+
+constexpr uint32_t kBlock = 256;            // threads per workgroup (4 wavefronts)
+constexpr uint32_t kWavesPerBlock = kBlock / 64;
+constexpr uint32_t kChunkPairs = 256;       // triangle pairs per k_mesh job (512 triangles)
+constexpr uint32_t kMeshGrid = 256 * 8;     // persistent k_mesh grid: 8 workgroups per CU
+constexpr uint32_t kShards = 64;            // ray-queue shards = lanes of a wavefront
+// Every atomically updated counter sits on a 128-byte line of its own: atomics
+// to one line serialise, whatever word of it they touch.
+constexpr uint32_t kCountStride = 32;
+constexpr uint32_t kCastShards = 1024;      // statistics counters per path kernel: one atomic per wavefront, spread over 1024 lines
+constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none)
+constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
+constexpr uint32_t kMaxLights = 64;
+constexpr uint32_t kClusterPairs = 32;      // triangle pairs per culling cluster (64 triangles)
+constexpr uint32_t kGroupClusters = 64;     // clusters per group (second level of the culling hierarchy)
+constexpr uint32_t kMaxClusters = kGroupClusters * 64; // 4096 clusters = 262 144 triangles; larger meshes get larger clusters
+constexpr size_t kClusterListBudget = size_t(24) << 30; // most bytes the per-cluster ray lists may take (of 288 GB)
+
+constexpr uint32_t F_ALIVE = 1u;   // the path still bounces
+constexpr uint32_t F_PENDING = 2u; // pend[] holds light contributions of the last hit
+constexpr uint32_t F_EARLY = 4u;   // the reference's terminate_early for this sample
+
+constexpr float PEND_NONE = -2.f;   // slot unused
+constexpr float PEND_ALWAYS = -1.f; // contribution known to be visible
+
+// Structure-of-arrays scene in HBM.  Every array is read with a wave-uniform
+// index except tri_shade / mat_* at shading time.
+struct DeviceScene {
+    const float4* sphere;     // centre.xyz, radius
+    const int32_t* sphere_mat;
+    const float4* mat_color;  // colour.xyz, type as int bits
+    const float2* mat_ior;    // ro, ri
+    const float4* tri_geom;   // 3 per triangle: A.xyz e1.x | e1.yz e2.xy | e2.z N.xyz
+    const float2* tri_pair;   // 12 per PAIR of triangles (2j, 2j+1): A.x A.y A.z e1.xyz e2.xyz N.xyz,
+                              // each as (value of 2j, value of 2j+1); k_mesh streams this one
+    const uint32_t* tri_orig; // caller's index of the triangle at each position of tri_pair
+                              // (triangles are stored in Morton order of their centroids)
+    const float2* cl_pair;    // padded bounds of each cluster of cluster_pairs consecutive pairs,
+                              // 6 per PAIR of clusters (2k, 2k+1): lo.x lo.y lo.z hi.x hi.y hi.z
+    const float2* grp_pair;   // the same for groups of kGroupClusters consecutive clusters (meshes of more than 64 clusters)
+    const float4* tri_shade;  // 3 per triangle: n0.xyz material | n1.xyz - | n2.xyz -
+    const float4* box_min;
+    const float4* box_max;
+    const float4* light;      // position.xyz, intensity
+    uint32_t n_spheres, n_triangles, n_boxes, n_lights;
+    uint32_t n_clusters, cluster_pairs, n_groups;
+};
+
+// Per-batch path state and queues.
+struct Work {
+    float4* ray_o;   // origin.xyz, nearest-sphere distance
+    float4* ray_d;   // direction.xyz, nearest-sphere index as int bits
+    float4* thr;     // albedo.xyz, next random dimension as uint bits
+    float4* rad;     // colour L.xyz, F_* flags as uint bits
+    float4* pend;    // n_lights per path: contribution.xyz, light distance or PEND_*
+    unsigned long long* hit; // paths + paths*n_lights slots: (t bits << 32) | triangle
+    float4* q_o;     // queued ray origin.xyz, hit slot as uint bits
+    float4* q_d;     // queued ray direction.xyz, cut-off distance
+    uint32_t* q_count; // kShards counters (kCountStride words apart) per k_mesh stage of a batch
+    uint32_t* cast_count; // statistics: kCastShards counters (kCountStride words apart) per path kernel of a batch
+    uint32_t shard_capacity; // queue entries reserved per shard
+    // cluster culling: per stage slot, the queue positions of the rays that touch each cluster
+    uint32_t* cl_count;      // n_clusters counters per slot
+    uint32_t* cl_list;       // n_clusters lists of list_capacity queue positions (reused by every slot)
+    uint32_t* grp_count;     // the same three for the groups of clusters
+    uint32_t* grp_list;
+    uint32_t list_capacity;  // = rays binned per tile
+};
+
+struct V3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+// scalar of type double: product in double, one rounding to float
+// (reference include/vector.cuh:153-160 with S = double)
+__device__ __forceinline__ V3 scale_d(double s, V3 a) {
+    return mk((float)(s * (double)a.x), (float)(s * (double)a.y), (float)(s * (double)a.z));
+}
+// in-order dot product.  The reference starts the sum at 0.f
+// (include/vector.cuh:179-183); 0.f + p equals p except that it turns -0 into
+// +0, which no consumer of these dots can observe (they feed squares,
+// comparisons against 0 and quotients that are rejected when the divisor is
+// a zero of either sign).
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// the same with the explicit leading zero, for the few places that divide by
+// the result of a dot with an axis vector
+__device__ __forceinline__ float dot_z(V3 a, V3 b) { return ((0.f + a.x * b.x) + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float norm(V3 a) { return sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ __forceinline__ V3 normalize(V3 a) {
+    const float n = norm(a);
+    return mk(a.x / n, a.y / n, a.z / n);
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
+
+// ---------------------------------------------------------- intersection
+
+// The first kSphereCache spheres of the scene, staged in LDS by the kernels
+// that test every sphere for every path: the index is wave-uniform, so an LDS
+// read is a broadcast, whereas a global load (which the compiler cannot turn
+// into a scalar load in kernels that also write global memory) stalls every
+// iteration on the vector memory path.
+constexpr uint32_t kSphereCache = 64;
+
+struct Spheres {
+    const float4* lds;
+    const float4* global;
+    uint32_t cached, n;
+    __device__ __forceinline__ float4 operator[](uint32_t i) const { return i < cached ? lds[i] : global[i]; }
+};
+
+// All threads of the workgroup must call it.
+__device__ __forceinline__ Spheres stage_spheres(const DeviceScene& sc, float4* lds) {
+    Spheres s;
+    s.lds = lds;
+    s.global = sc.sphere;
+    s.n = sc.n_spheres;
+    s.cached = s.n < kSphereCache ? s.n : kSphereCache;
+    for (uint32_t i = threadIdx.x; i < s.cached; i += kBlock) lds[i] = sc.sphere[i];
+    __syncthreads();
+    return s;
+}
+
+// One sphere of the reference's scan (get_distance, src/raytrace.cu:59-84)
+// given b = u . OC and n2 = |OC| * |OC|.
+__device__ __forceinline__ void sphere_step(float b, float n2, float R, uint32_t i, float& min_dist, int& id) {
+    const float delta = b * b - n2 + R * R;
+    if (delta >= 0) {
+        const float sq = sqrtf(delta);
+        const float t2 = -b + sq;
+        if (t2 >= 0) {
+            const float t1 = -b - sq;
+            const float t = t1 >= 0 ? t1 : t2;
+            if (id < 0 || t < min_dist) { min_dist = t; id = (int)i; }
+        }
+    }
+}
+
+// Nearest sphere along a ray (reference get_distance, src/raytrace.cu:53-87).
+__device__ __forceinline__ float nearest_sphere(const Spheres& sp, V3 ray, V3 start, int& id) {
+    float min_dist = INFINITY;
+    for (uint32_t i = 0; i < sp.n; i++) {
+        const float4 s = sp[i];
+        const V3 oc = start - xyz(s);
+        const float ocn = norm(oc);
+        sphere_step(dot(ray, oc), ocn * ocn, s.w, i, min_dist, id);
+    }
+    return min_dist;
+}
+
+// The same scan for two rays that leave the same point (a shadow ray and the
+// bounce ray of one hit): OC and its norm depend on the start only and are
+// computed once per sphere.  A ray whose flag is false keeps (inf, id).
+__device__ __forceinline__ void nearest_sphere_pair(const Spheres& sp, V3 start, bool do_a, V3 ray_a, float& dist_a, int& id_a,
+                                                    bool do_b, V3 ray_b, float& dist_b, int& id_b) {
+    dist_a = INFINITY;
+    dist_b = INFINITY;
+    for (uint32_t i = 0; i < sp.n; i++) {
+        const float4 s = sp[i];
+        const V3 oc = start - xyz(s);
+        const float ocn = norm(oc);
+        const float n2 = ocn * ocn;
+        if (do_a) sphere_step(dot(ray_a, oc), n2, s.w, i, dist_a, id_a);
+        if (do_b) sphere_step(dot(ray_b, oc), n2, s.w, i, dist_b, id_b);
+    }
+}
+
+// One box of the scan below for a ray, given lo = box_min - start, hi = box_max - start.
+__device__ __forceinline__ bool box_hit(V3 lo, V3 hi, V3 ray) {
+    const V3 axis[3] = {mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1)};
+    float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float rdn = dot_z(ray, axis[i]);
+        if (rdn != 0) {
+            const float a = dot_z(lo, axis[i]) / rdn;
+            const float b = dot_z(hi, axis[i]) / rdn;
+            if (a < b) { t0[i] = a; t1[i] = b; }
+            else       { t0[i] = b; t1[i] = a; }
+        }
+    }
+    // running min / max seeded with element 0 (reference include/vector.cuh:69-85)
+    float mn = t1[0];
+    if (t1[1] < mn) mn = t1[1];
+    if (t1[2] < mn) mn = t1[2];
+    float mx = t0[0];
+    if (t0[1] > mx) mx = t0[1];
+    if (t0[2] > mx) mx = t0[2];
+    return mn > mx;
+}
+
+// Slab test against every box until one is hit (reference
+// src/raytrace.cu:103-145): per axis the entry/exit parameters stay 0 when
+// the ray is parallel to the slab, there is no t > 0 requirement, and the
+// verdict is min(exit) > max(entry).
+__device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, V3 ray, V3 start) {
+    for (uint32_t o = 0; o < sc.n_boxes; o++)
+        if (box_hit(xyz(sc.box_min[o]) - start, xyz(sc.box_max[o]) - start, ray)) return true;
+    return false;
+}
+
+// Appends the rays of the lanes with want == true to the k_mesh queue: one
+// atomic per wavefront, slots in lane order.  The queue is split into kShards
+// shards with a counter each and a wavefront always uses the shard of its own
+// index, which spreads the returning atomics over 64 addresses (one address
+// serialises at well under 200 atomics per microsecond).
+// Returns the queue position of this lane's ray (0 when want == false).
+__device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, bool want, V3 start, V3 ray, uint32_t slot, float cutoff) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return 0;
+    const uint32_t lane = __lane_id();
+    const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&w.q_count[(counter * kShards + shard) * kCountStride], (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    uint32_t at = 0;
+    if (want) {
+        at = shard * w.shard_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
+        w.q_o[at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot));
+        w.q_d[at] = make_float4(ray.x, ray.y, ray.z, cutoff);
+    }
+    return at;
+}
+
+// Statistics: adds n (the wavefront's number of rays tested against the
+// spheres in this kernel) to one of the kernel's counters.  All lanes pass the
+// same n.
+__device__ __forceinline__ void add_casts(const Work& w, uint32_t counter, uint32_t n) {
+    if (n && __lane_id() == 0) {
+        const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kCastShards;
+        atomicAdd(&w.cast_count[((size_t)counter * kCastShards + shard) * kCountStride], n);
+    }
+}
+
+// True when the ray has to walk the triangle list (reference
+// src/raytrace.cu:103-146: with boxes enabled only after a box hit).
+__device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, int use_boxes, V3 ray, V3 start) {
+    if (sc.n_triangles == 0) return false;
+    if (!use_boxes) return true;
+    return any_box_hit(sc, ray, start);
+}
+
+// needs_mesh for two rays that leave the same point; box - start is shared.
+__device__ __forceinline__ void needs_mesh_pair(const DeviceScene& sc, int use_boxes, V3 start, bool do_a, V3 ray_a, bool& walk_a,
+                                                bool do_b, V3 ray_b, bool& walk_b) {
+    walk_a = false;
+    walk_b = false;
+    if (sc.n_triangles == 0) return;
+    if (!use_boxes) { walk_a = do_a; walk_b = do_b; return; }
+    for (uint32_t o = 0; o < sc.n_boxes; o++) {
+        const V3 lo = xyz(sc.box_min[o]) - start;
+        const V3 hi = xyz(sc.box_max[o]) - start;
+        if (do_a && !walk_a) walk_a = box_hit(lo, hi, ray_a);
+        if (do_b && !walk_b) walk_b = box_hit(lo, hi, ray_b);
+    }
+}
+
+// Barycentrics of a known hit, by the expressions of the reference's triangle
+// loop (src/raytrace.cu:155-164).
+__device__ __forceinline__ void barycentrics(const DeviceScene& sc, int tri, V3 ray, V3 start, float& alpha, float& beta, float& gamma) {
+    const float4 g0 = sc.tri_geom[3 * tri + 0], g1 = sc.tri_geom[3 * tri + 1], g2 = sc.tri_geom[3 * tri + 2];
+    const V3 A = mk(g0.x, g0.y, g0.z), e1 = mk(g0.w, g1.x, g1.y), e2 = mk(g1.z, g1.w, g2.x), N = mk(g2.y, g2.z, g2.w);
+    const V3 q = cross(A - start, ray);
+    const float d = dot(ray, N);
+    beta = dot(e2, q) / d;
+    gamma = -dot(e1, q) / d;
+    alpha = 1.f - beta - gamma;
+}
+
+} // namespace

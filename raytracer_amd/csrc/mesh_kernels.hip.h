@@ -1,0 +1,487 @@
+// mesh_kernels.hip.h -- the triangle kernels: exhaustive scan (k_mesh) and cluster culling (k_bin64, k_bin_groups, k_mesh_clusters).
+// Part of the device half of librt_amd.so; included by pathtrace.hip only.
+#pragma once
+
+#include "device_scene.hip.h"
+
+namespace {
+
+// ------------------------------------------------------------- k_mesh
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Nearest hit of a lane so far.  `t` is the ray's cut-off distance while
+// index < 0 (nearest sphere hit for a bounce ray, light distance for a shadow
+// ray: a triangle at or beyond it cannot change the outcome, because spheres
+// win ties, src/raytrace.cu:203-212, and a shadow ray asks for t < distance,
+// :240).  Once a triangle is held, `t` is its distance to within a few 1e-7
+// (relative) and the exact value is the IEEE quotient num / den, which
+// hit_distance() evaluates once, after the scan.  `index` is the triangle's
+// POSITION in the scan order; tri_orig maps it to the caller's index.
+struct Nearest {
+    float t, num, den;
+    int index;
+};
+
+// tri_orig[pos] through the vector memory path.  `pos` is wave-uniform inside
+// the scan, so the compiler would use a scalar load, and waiting for a scalar
+// load also waits for the prefetch of the next triangle pair (scalar loads
+// return out of order: the only wait is "all of them").  Used on the rare
+// exact-tie path only.
+__device__ __forceinline__ int orig_index(const uint32_t* __restrict__ tri_orig, int pos) {
+    const uint32_t* p = tri_orig + pos;
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return (int)v;
+}
+
+__device__ __forceinline__ Nearest nearest_init(float cutoff) { Nearest n; n.t = cutoff; n.num = 0.f; n.den = 1.f; n.index = -1; return n; }
+__device__ __forceinline__ float hit_distance(const Nearest& n) { return n.num / n.den; }
+
+// Exact comparison (reference src/raytrace.cu:164-174): t = (A-O).N / u.N must
+// be positive and nearer than the nearest so far; among equal distances the
+// lower caller's triangle index wins, as in the reference's in-order scan.
+__device__ __forceinline__ void take_if_nearer_exact(float ao_dot_n, float d, uint32_t pos, const uint32_t* __restrict__ tri_orig, Nearest& best) {
+    const float t = ao_dot_n / d;
+    const float held = best.index >= 0 ? hit_distance(best) : best.t;
+    if (t > 0 && (t < held || (t == held && best.index >= 0 && orig_index(tri_orig, (int)pos) < orig_index(tri_orig, best.index)))) {
+        best.t = t; best.num = ao_dot_n; best.den = d; best.index = (int)pos;
+    }
+}
+
+// Exact tail of one ray-triangle test (reference src/raytrace.cu:161-174),
+// entered only by lanes the division-free test could neither reject nor
+// accept.
+__device__ __forceinline__ void exact_hit(float nb, float ng, float d, float ao_dot_n, uint32_t pos, const uint32_t* __restrict__ tri_orig, Nearest& best) {
+    const float beta = nb / d;
+    const float gamma = -ng / d;
+    const float alpha = 1.f - beta - gamma;
+    if (alpha >= 0 && beta >= 0 && gamma >= 0) take_if_nearer_exact(ao_dot_n, d, pos, tri_orig, best);
+}
+
+// A lane the division-free test could not reject.  `lo` is the smallest of the
+// approximate alpha, beta, gamma (each within 1e-6 of the exact value when the
+// point is inside).  lo >= 1e-5 means the reference's exact values are all
+// positive, so the hit is accepted without computing them.  Its approximate
+// distance t_ = (A-O).N * rcp(u.N) is within 3e-7 (relative) of the exact
+// quotient, as is the held one, so a factor 1 + 2e-6 between them decides the
+// order without a division; a negative t_ has a non-positive exact quotient.
+// Near-ties, values too small for the error bound and NaNs are decided
+// exactly.  Anything closer to an edge takes exact_hit.
+__device__ __forceinline__ void candidate(float lo, float nb, float ng, float d, float rcp, float ao_dot_n, uint32_t pos,
+                                          const uint32_t* __restrict__ tri_orig, Nearest& best) {
+    if (lo >= 1e-5f) {
+        const float t_ = ao_dot_n * rcp;
+        if (t_ > best.t * 1.000002f || t_ < 0.f) return;
+        if (t_ * 1.000002f < best.t && t_ > 1e-30f) {
+            best.t = t_; best.num = ao_dot_n; best.den = d; best.index = (int)pos;
+        } else {
+            take_if_nearer_exact(ao_dot_n, d, pos, tri_orig, best);
+        }
+    } else {
+        exact_hit(nb, ng, d, ao_dot_n, pos, tri_orig, best);
+    }
+}
+
+// Twelve packed values of one triangle pair: A.xyz, e1.xyz, e2.xyz, N.xyz.
+struct PairData {
+    f2 v[12];
+};
+
+__device__ __forceinline__ PairData load_pair(const f2* __restrict__ tri2, uint32_t j) {
+    PairData p;
+    const f2* __restrict__ g = tri2 + 12 * (size_t)j;
+#pragma unroll
+    for (int k = 0; k < 12; k++) p.v[k] = g[k];
+    return p;
+}
+
+// One ray (lane) against the two triangles of a pair.  The numerators e2.q,
+// e1.q and the denominator u.N are computed with the reference's operation
+// order (src/raytrace.cu:155-162), two triangles at a time in packed fp32.
+// The division-free test uses an approximate reciprocal: a hit the reference
+// accepts has alpha, beta, gamma in [0, 1], where the approximations are off
+// by < 1e-6, so the 1e-5 margin never drops one; a NaN passes.
+__device__ __forceinline__ void test_pair(const PairData& p, const uint32_t* __restrict__ tri_orig, uint32_t pos, float ox, float oy, float oz,
+                                          float ux, float uy, float uz, Nearest& best) {
+    const f2 Ax = p.v[0], Ay = p.v[1], Az = p.v[2];
+    const f2 e1x = p.v[3], e1y = p.v[4], e1z = p.v[5];
+    const f2 e2x = p.v[6], e2y = p.v[7], e2z = p.v[8];
+    const f2 Nx = p.v[9], Ny = p.v[10], Nz = p.v[11];
+    const f2 aox = Ax - ox, aoy = Ay - oy, aoz = Az - oz;
+    const f2 qx = aoy * uz - aoz * uy;
+    const f2 qy = aoz * ux - aox * uz;
+    const f2 qz = aox * uy - aoy * ux;
+    const f2 d = (ux * Nx + uy * Ny) + uz * Nz;
+    const f2 nb = (e2x * qx + e2y * qy) + e2z * qz; // e2 . q
+    const f2 ng = (e1x * qx + e1y * qy) + e1z * qz; // e1 . q
+    f2 rcp;
+    rcp.x = __builtin_amdgcn_rcpf(d.x);
+    rcp.y = __builtin_amdgcn_rcpf(d.y);
+    const f2 b_ = nb * rcp;
+    const f2 g_ = -ng * rcp;
+    const f2 a_ = (1.f - b_) - g_;
+    const float lo0 = fminf(fminf(a_.x, b_.x), g_.x);
+    const float lo1 = fminf(fminf(a_.y, b_.y), g_.y);
+    const bool c0 = !(lo0 < -1e-5f), c1 = !(lo1 < -1e-5f);
+    if (c0 || c1) {
+        // one divergent region for both triangles: a lane brings the first of its candidates
+        // (lower position first, as in the scan), the rare second one follows
+        const f2 aon = (aox * Nx + aoy * Ny) + aoz * Nz;
+        if (c0) candidate(lo0, nb.x, ng.x, d.x, rcp.x, aon.x, pos, tri_orig, best);
+        else    candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, pos + 1, tri_orig, best);
+        if (c0 && c1) candidate(lo1, nb.y, ng.y, d.y, rcp.y, aon.y, pos + 1, tri_orig, best);
+    }
+}
+
+// Lane l of every wavefront holds shard l's ray count and the number of
+// 256-ray blocks in the shards before it.
+struct ShardMap {
+    uint32_t my_count, before, n_ray_blocks;
+};
+
+__device__ __forceinline__ ShardMap load_shard_map(const uint32_t* __restrict__ q_count) {
+    ShardMap m;
+    const uint32_t lane = __lane_id();
+    m.my_count = q_count[lane * kCountStride];
+    const uint32_t my_blocks = (m.my_count + kBlock - 1) / kBlock;
+    uint32_t incl = my_blocks;
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) {
+        const uint32_t up = __shfl_up(incl, step);
+        if ((int)lane >= step) incl += up;
+    }
+    m.before = incl - my_blocks;
+    m.n_ray_blocks = __shfl(incl, 63);
+    return m;
+}
+
+// Queue position of this lane's ray in ray block `ray_block`; lanes past the
+// end of the shard get the shard's last ray and active = false.
+__device__ __forceinline__ uint32_t ray_position(const ShardMap& m, uint32_t ray_block, uint32_t shard_capacity, bool& active) {
+    const uint32_t shard = (uint32_t)__popcll(__ballot(m.before <= ray_block)) - 1u; // `before` is non-decreasing
+    const uint32_t shard_first = __shfl(m.before, (int)shard);
+    const uint32_t count = __shfl(m.my_count, (int)shard);
+    const uint32_t r = (ray_block - shard_first) * kBlock + threadIdx.x;
+    active = r < count;
+    return shard * shard_capacity + (active ? r : count - 1);
+}
+
+// One ray per lane against triangle pairs [first, last): two pairs per trip,
+// two SGPR sets.  Scalar loads return out of order, so the only wait available
+// is "all of them": each set is therefore requested right after an explicit
+// wait and just before the OTHER set is tested, which leaves exactly one
+// request in flight during a test.  Indices past the end are clamped and
+// their tests skipped.
+__device__ __forceinline__ void scan_pairs(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t first,
+                                           uint32_t last, float ox, float oy, float oz, float ux, float uy, float uz,
+                                           Nearest& best) {
+    PairData cur = load_pair(tri2, first);
+    for (uint32_t j = first; j < last; j += 2) {
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): `cur` has landed
+        const PairData nxt = load_pair(tri2, min(j + 1, last - 1));
+        __builtin_amdgcn_sched_barrier(0); // keep the request ahead of the test it overlaps
+        test_pair(cur, tri_orig, 2 * j, ox, oy, oz, ux, uy, uz, best);
+        __builtin_amdgcn_s_waitcnt(0xC07F); // `nxt` has landed
+        cur = load_pair(tri2, min(j + 2, last - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < last) test_pair(nxt, tri_orig, 2 * j + 2, ox, oy, oz, ux, uy, uz, best);
+    }
+}
+
+// Every queued ray against every triangle (reference src/raytrace.cu:148-175).
+//
+// A lane owns a ray; the triangle index is wave-uniform, so triangle data
+// arrives by scalar loads and stays in SGPRs.  Two triangles are tested per
+// iteration with packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 work on
+// a register pair at the issue cost of one instruction): tri_pair holds every
+// quantity as (triangle 2j, triangle 2j+1), the ray components are broadcast.
+//
+// A job is 256 rays x one chunk of triangle pairs.  The nearest hit per ray is
+// merged across chunks with a 64-bit atomic minimum on (t bits, triangle),
+// which orders by distance first and triangle index second: the reference's
+// "first triangle wins ties".  Jobs are dealt so that the chunks of one ray
+// block run on workgroups with equal blockIdx % 8, which share an L2.
+__global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
+                                                 const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                 const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
+                                                 unsigned long long* __restrict__ hit) {
+    const ShardMap map = load_shard_map(q_count);
+    if (map.n_ray_blocks == 0) return;
+    const uint32_t n_pairs = (n_tri + 1) / 2;
+    const uint32_t n_chunks = (n_pairs + kChunkPairs - 1) / kChunkPairs;
+    const uint32_t xcd = blockIdx.x % 8;
+    const uint32_t per_xcd = ((map.n_ray_blocks + 7) / 8) * n_chunks;
+    for (uint32_t q = blockIdx.x / 8; q < per_xcd; q += gridDim.x / 8) {
+        const uint32_t ray_block = (q / n_chunks) * 8 + xcd;
+        if (ray_block >= map.n_ray_blocks) continue;
+        const uint32_t chunk = q % n_chunks;
+        bool active;
+        const uint32_t at = ray_position(map, ray_block, shard_capacity, active);
+        const float4 o4 = q_o[at];
+        const float4 d4 = q_d[at];
+        Nearest best = nearest_init(d4.w);
+        const uint32_t first = chunk * kChunkPairs;
+        scan_pairs(tri2, tri_orig, first, min(first + kChunkPairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
+        if (active && best.index >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | tri_orig[best.index];
+            atomicMin(&hit[__float_as_uint(o4.w)], key);
+        }
+    }
+}
+
+// ---- cluster culling ------------------------------------------------------
+//
+// The reference tests every triangle once any object box is hit
+// (src/raytrace.cu:136-148).  A triangle can only be hit by a ray that passes
+// through the (padded) bounds of the cluster of 64 spatially adjacent
+// triangles it belongs to, before the ray's cut-off distance.  k_bin64 lists,
+// per cluster, the queued rays that do; k_mesh_clusters turns the list lengths
+// into job offsets (plan_jobs) and runs the same pair scan as k_mesh over each
+// cluster's list.  A mesh of more than 64 clusters gets a second level: groups
+// of 64 consecutive clusters (neighbours in space, the triangles being in
+// Morton order) with the union of their bounds; k_bin64 lists the rays per
+// group and k_bin_groups bins each group's list into its clusters, so a ray
+// is tested against 64 boxes per level instead of against every cluster --
+// a 64-ary bounding-volume hierarchy walked breadth first.  The image is the exhaustive scan's, bit for bit, unless the
+// reference's own rounding makes it accept a triangle for a ray that misses
+// the triangle by more than the padding (a grazing ray whose barycentrics are
+// rounding noise); rt_options.cluster_culling = 0 selects the exhaustive scan.
+
+// Index of the last entry of first[0..n) that is <= job (entries are
+// non-decreasing; empty ranges share their successor's value).
+__device__ __forceinline__ uint32_t owner_of_job(const uint32_t* first, uint32_t n, uint32_t job) {
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) / 2;
+        if (first[mid] <= job) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// first_job[i] = number of 256-entry jobs of the lists before list i,
+// first_job[n] = their total, from the list lengths (count[i * kCountStride]);
+// n <= kMaxClusters.  Every workgroup of a kernel that walks the lists makes
+// its own copy in LDS (`scan` is kBlock words of scratch): the lengths sit in
+// L2 and the scan is a few microseconds, less than a launch of its own would
+// cost.  All threads of the workgroup must call it.
+__device__ __forceinline__ void plan_jobs(const uint32_t* __restrict__ count, uint32_t n, uint32_t* first_job, uint32_t* scan) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n + kBlock - 1) / kBlock; // consecutive lists per thread, at most 16
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = t * per + k;
+        if (i < n) mine += (count[(size_t)i * kCountStride] + kBlock - 1) / kBlock;
+    }
+    scan[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < kBlock; off <<= 1) {
+        const uint32_t v = t >= off ? scan[t - off] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = scan[t] - mine;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = t * per + k;
+        if (i < n) {
+            first_job[i] = run;
+            run += (count[(size_t)i * kCountStride] + kBlock - 1) / kBlock;
+        }
+    }
+    if (t == kBlock - 1) first_job[n] = scan[t];
+    __syncthreads();
+}
+
+// The hardware minimum / maximum: a NaN operand is dropped (minNum / maxNum).
+// Written as instructions because the library functions first re-quiet every
+// operand (v_max x, x), which doubles the cost of a slab test.
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// One ray prepared for slab tests: 1/u, origin * (1/u), cut-off distance.
+struct SlabRay {
+    float ix, iy, iz, ox, oy, oz, cutoff;
+};
+
+__device__ __forceinline__ SlabRay slab_ray(float4 o4, float4 d4) {
+    SlabRay r;
+    r.ix = 1.f / d4.x; r.iy = 1.f / d4.y; r.iz = 1.f / d4.z; // +-inf for an axis-parallel ray
+    r.ox = o4.x * r.ix; r.oy = o4.y * r.iy; r.oz = o4.z * r.iz;
+    r.cutoff = d4.w;
+    return r;
+}
+
+// Slab tests of R rays per lane against box pairs [first, last), last - first
+// <= 16: bit 2(k - first) + h of bits[i] is set when ray i enters box h of
+// pair k before its cut-off distance.  The slab parameters come from packed
+// FMAs (t = bound * (1/u) - origin * (1/u)); this is only a filter and need not
+// follow the reference's rounding.  NaN (inf - inf on an axis-parallel ray) is
+// dropped by the minimum / maximum, which errs towards "touches".  The box
+// data of an iteration (scalar loads) serves all R rays.
+template <int R>
+__device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint32_t first, uint32_t last, const SlabRay (&ray)[R],
+                                          uint32_t (&bits)[R]) {
+#pragma unroll
+    for (int i = 0; i < R; i++) bits[i] = 0;
+    for (uint32_t k = first; k < last; k++) {
+        const f2* __restrict__ b = box_pair + 6 * (size_t)k;
+        const f2 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
+        const uint32_t bit = 1u << (2 * (k - first)); // wave-uniform
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const SlabRay& r = ray[i];
+            const f2 ax = __builtin_elementwise_fma(b0, (f2)(r.ix), (f2)(-r.ox)), bx = __builtin_elementwise_fma(b3, (f2)(r.ix), (f2)(-r.ox));
+            const f2 ay = __builtin_elementwise_fma(b1, (f2)(r.iy), (f2)(-r.oy)), by = __builtin_elementwise_fma(b4, (f2)(r.iy), (f2)(-r.oy));
+            const f2 az = __builtin_elementwise_fma(b2, (f2)(r.iz), (f2)(-r.oz)), bz = __builtin_elementwise_fma(b5, (f2)(r.iz), (f2)(-r.oz));
+            const float in0 = hw_max3(hw_min(ax.x, bx.x), hw_min(ay.x, by.x), hw_min(az.x, bz.x));
+            const float out0 = hw_min3(hw_max(ax.x, bx.x), hw_max(ay.x, by.x), hw_max(az.x, bz.x));
+            const float in1 = hw_max3(hw_min(ax.y, bx.y), hw_min(ay.y, by.y), hw_min(az.y, bz.y));
+            const float out1 = hw_min3(hw_max(ax.y, bx.y), hw_max(ay.y, by.y), hw_max(az.y, bz.y));
+            const bool t0 = (out0 >= hw_max(in0, 0.f)) & (in0 <= r.cutoff);
+            const bool t1 = (out1 >= hw_max(in1, 0.f)) & (in1 <= r.cutoff);
+            bits[i] |= (t0 ? bit : 0u) | (t1 ? bit << 1 : 0u);
+        }
+    }
+}
+
+// Bins R rays per lane (queue positions at[i], ignored when !active[i])
+// against up to 64 padded boxes and appends each position to the list of every
+// box its ray enters before its cut-off distance.  One pass over the boxes: a
+// lane keeps the boxes a ray touches as a 64-bit mask; then every lane walks
+// the set bits of its masks twice -- to count per box in LDS (`slot`, 64
+// words), and, after the workgroup has reserved list space with one atomic per
+// box, to take its positions.  All threads of the workgroup must call it.
+template <int R>
+__device__ __forceinline__ void bin_prepared64(const f2* __restrict__ box_pair, uint32_t n_boxes, const bool (&active)[R], const uint32_t (&at)[R],
+                                               const SlabRay (&ray)[R], uint32_t* __restrict__ count, uint32_t* __restrict__ list,
+                                               uint32_t list_capacity, uint32_t* slot) {
+    if (threadIdx.x < 64) slot[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n_pairs = (n_boxes + 1) / 2;
+    // boxes 0-31 and 32-63 each ray touches
+    uint32_t bits_lo[R], bits_hi[R];
+    slab_bits<R>(box_pair, 0, min(n_pairs, 16u), ray, bits_lo);
+    slab_bits<R>(box_pair, 16, max(n_pairs, 16u), ray, bits_hi);
+    // an odd box count leaves the second half of the last entry without a box: drop its bit
+    const unsigned long long real = n_boxes >= 64 ? ~0ULL : (1ULL << n_boxes) - 1ULL;
+    unsigned long long mine[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        mine[i] = active[i] ? ((((unsigned long long)bits_hi[i] << 32) | bits_lo[i]) & real) : 0ULL;
+        for (unsigned long long m = mine[i]; m; m &= m - 1) atomicAdd(&slot[(uint32_t)__ffsll((long long)m) - 1u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_boxes) {
+        const uint32_t total = slot[threadIdx.x];
+        slot[threadIdx.x] = total ? atomicAdd(&count[threadIdx.x * kCountStride], total) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R; i++)
+        for (unsigned long long m = mine[i]; m; m &= m - 1) {
+            const uint32_t c = (uint32_t)__ffsll((long long)m) - 1u;
+            list[(size_t)c * list_capacity + atomicAdd(&slot[c], 1u)] = at[i];
+        }
+    __syncthreads();
+}
+
+// The same for rays read back from the queue.
+template <int R>
+__device__ __forceinline__ void bin_rays64(const f2* __restrict__ box_pair, uint32_t n_boxes, const bool (&active)[R], const uint32_t (&at)[R],
+                                           const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                           uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity,
+                                           uint32_t* slot) {
+    SlabRay ray[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) ray[i] = slab_ray(q_o[at[i]], q_d[at[i]]);
+    bin_prepared64<R>(box_pair, n_boxes, active, at, ray, count, list, list_capacity, slot);
+}
+
+// First level: the queued rays of one tile (256-ray blocks [first_block,
+// first_block + blocks_in_tile)) against the clusters of a mesh of at most 64
+// clusters, or against the groups of a larger one.  A workgroup takes R
+// consecutive ray blocks at a time (R rays per lane): two halve the barriers
+// and reservations per ray, one keeps more workgroups busy when the queue is
+// short.
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ box_pair, uint32_t n_boxes,
+                                                  const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                  const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
+                                                  uint32_t first_block, uint32_t blocks_in_tile,
+                                                  uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity) {
+    __shared__ uint32_t slot[64];
+    const ShardMap map = load_shard_map(q_count);
+    const uint32_t end = min(first_block + blocks_in_tile, map.n_ray_blocks);
+    for (uint32_t ray_block = first_block + R * blockIdx.x; ray_block < end; ray_block += R * gridDim.x) {
+        bool active[R];
+        uint32_t at[R];
+        at[0] = ray_position(map, ray_block, shard_capacity, active[0]);
+#pragma unroll
+        for (int i = 1; i < R; i++) {
+            if (ray_block + i < end) {
+                at[i] = ray_position(map, ray_block + i, shard_capacity, active[i]);
+            } else {
+                at[i] = at[0];
+                active[i] = false;
+            }
+        }
+        bin_rays64<R>(box_pair, n_boxes, active, at, q_o, q_d, count, list, list_capacity, slot);
+    }
+}
+
+// Second level: the rays on each group's list against the (at most 64)
+// clusters of that group.  A job is 256 list entries of one group.
+__global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl_pair, uint32_t n_clusters, uint32_t n_groups,
+                                                       const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                       const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_list,
+                                                       uint32_t* __restrict__ cl_count, uint32_t* __restrict__ cl_list, uint32_t list_capacity) {
+    __shared__ uint32_t slot[64];
+    __shared__ uint32_t first_job[64 + 1];
+    __shared__ uint32_t scan[kBlock];
+    plan_jobs(grp_count, n_groups, first_job, scan);
+    const uint32_t n_jobs = first_job[n_groups];
+    for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+        const uint32_t g = owner_of_job(first_job, n_groups, job);
+        const uint32_t count = grp_count[g * kCountStride];
+        const uint32_t e = (job - first_job[g]) * kBlock + threadIdx.x;
+        const bool active[1] = {e < count};
+        const uint32_t at[1] = {grp_list[(size_t)g * list_capacity + (active[0] ? e : count - 1)]};
+        const uint32_t first_cluster = g * kGroupClusters;
+        bin_rays64<1>(cl_pair + 6 * (size_t)(first_cluster / 2), min(kGroupClusters, n_clusters - first_cluster), active, at, q_o, q_d,
+                   cl_count + (size_t)first_cluster * kCountStride, cl_list + (size_t)first_cluster * list_capacity, list_capacity, slot);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
+                                                          uint32_t n_clusters, uint32_t cluster_pairs,
+                                                          const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                          const uint32_t* __restrict__ cl_count,
+                                                          const uint32_t* __restrict__ cl_list, uint32_t list_capacity,
+                                                          unsigned long long* __restrict__ hit) {
+    __shared__ uint32_t first_job[kMaxClusters + 1];
+    __shared__ uint32_t scan[kBlock];
+    plan_jobs(cl_count, n_clusters, first_job, scan);
+    const uint32_t n_jobs = first_job[n_clusters];
+    const uint32_t n_pairs = (n_tri + 1) / 2;
+    for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+        const uint32_t c = owner_of_job(first_job, n_clusters, job);
+        const uint32_t count = cl_count[c * kCountStride];
+        const uint32_t e = (job - first_job[c]) * kBlock + threadIdx.x;
+        const bool active = e < count;
+        const uint32_t at = cl_list[(size_t)c * list_capacity + (active ? e : count - 1)];
+        const float4 o4 = q_o[at];
+        const float4 d4 = q_d[at];
+        Nearest best = nearest_init(d4.w);
+        const uint32_t first = c * cluster_pairs;
+        scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
+        if (active && best.index >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | tri_orig[best.index];
+            atomicMin(&hit[__float_as_uint(o4.w)], key);
+        }
+    }
+}
+
+} // namespace

@@ -1,0 +1,494 @@
+// path_kernels.hip.h -- the path kernels: camera samples (k_generate), one bounce (k_shade), accumulation and resolve, and the known-answer test kernels.
+// Part of the device half of librt_amd.so; included by pathtrace.hip only.
+#pragma once
+
+#include "device_scene.hip.h"
+
+namespace {
+
+// ------------------------------------------------------- path kernels
+
+struct Frame {
+    float rot[9];
+    float pos[3];
+    float fx, fy, cx, cy;
+    uint32_t width, n_pixels; // n_pixels = pixels rendered: the whole image, or a band of its rows
+    uint32_t pixel_offset;  // index of the band's first pixel in the image
+    uint32_t n_paths;       // paths in this batch = n_pixels * samples in batch
+    uint32_t sample_begin;  // global index of the batch's first sample
+    uint32_t seed;
+    int32_t indirect, antialiasing, bounding_box, max_depth;
+    int32_t count_casts;    // count the rays tested against the spheres (statistics)
+};
+
+__device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return f.pixel_offset + p % f.n_pixels; }
+__device__ __forceinline__ uint32_t path_sample(const Frame& f, uint32_t p) { return f.sample_begin + p / f.n_pixels; }
+
+// State write-back of a freshly generated ray whose nearest sphere (ts, sid)
+// and mesh verdict are known, and queueing for k_mesh.  All lanes of the
+// wavefront must call it.
+__device__ __forceinline__ uint32_t commit_ray(const Work& w, uint32_t counter, bool alive, uint32_t p, V3 start, V3 ray,
+                                               float ts, int sid, bool walk) {
+    if (alive) {
+        w.ray_o[p] = make_float4(start.x, start.y, start.z, ts);
+        w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
+        w.hit[p] = kNoHit;
+    }
+    return enqueue(w, counter, alive && walk, start, ray, p, ts);
+}
+
+// Nearest sphere + box test for a freshly generated ray, then commit_ray.
+__device__ __forceinline__ void launch_ray(const DeviceScene& sc, const Spheres& sp, const Work& w, const Frame& f, uint32_t counter,
+                                           bool alive, uint32_t p, V3 start, V3 ray) {
+    int sid = -1;
+    float ts = INFINITY;
+    bool walk = false;
+    if (alive) {
+        ts = nearest_sphere(sp, ray, start, sid);
+        walk = needs_mesh(sc, f.bounding_box, ray, start);
+    }
+    commit_ray(w, counter, alive, p, start, ray, ts, sid, walk);
+}
+
+// Camera sample of every path of the batch (reference src/raytrace.cu:479-494).
+//
+// With anti-aliasing the pixel offset is a Box-Muller pair that is redrawn
+// until both components are within half a pixel (src/raytrace.cu:33-42,
+// 483-486): 6.8 draws per path on average, but the slowest of 64 lanes needs
+// about 26, so a wavefront that keeps one path per lane idles three quarters
+// of its lanes.  A lane therefore owns kGenPaths paths and searches their
+// accepted draws back to back (first loop: lanes stay busy until the last
+// path of the slowest lane), and only the accepted draw of each path is
+// evaluated with the reference's arithmetic (second loop, all lanes together).
+//
+// The search classifies a draw with hardware transcendentals: r1 < 0.77 means
+// radius > 0.722, so one component exceeds 0.5 (max(|cos|,|sin|) >= 0.7071);
+// otherwise the approximate offsets (absolute error far below 1e-4) decide,
+// except within 1e-4 of the half-pixel limit, where the reference's own
+// arithmetic is evaluated.
+constexpr uint32_t kGenPaths = 4; // at most; short batches use fewer so that the grid still fills the chip
+
+__device__ __forceinline__ void jitter_exact(const rt_rng_key& key, uint32_t dim, float& dx, float& dy) {
+    const float r1 = rt_rng_uniform(key, dim);
+    const float r2 = rt_rng_uniform(key, dim + 1);
+    const float radius = sqrtf(-2 * rt_logf(r1));
+    const float angle = (float)(2 * M_PI * (double)r2);
+    float sn, cs;
+    rt_sincosf(angle, &sn, &cs);
+    dx = radius * cs * 1.f;
+    dy = radius * sn * 1.f;
+}
+
+template <uint32_t kPaths>
+__global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f) {
+    __shared__ float4 sphere_lds[kSphereCache];
+    __shared__ uint32_t key_kp[kPaths][kBlock], key_ks[kPaths][kBlock];
+    __shared__ uint32_t accepted[kPaths][kBlock]; // first dimension of the accepted draw
+    const Spheres sp = stage_spheres(sc, sphere_lds);
+    const uint32_t base = blockIdx.x * (kBlock * kPaths) + threadIdx.x;
+    // only this lane reads what it writes to the three arrays: no barrier needed
+    uint32_t owned = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < kPaths; r++) {
+        const uint32_t p = base + r * kBlock;
+        if (p < f.n_paths) {
+            const rt_rng_key key = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
+            key_kp[r][threadIdx.x] = key.kp;
+            key_ks[r][threadIdx.x] = key.ks;
+            accepted[r][threadIdx.x] = 0;
+            owned = r + 1; // paths are consecutive: a lane owns slots 0 .. owned-1
+        }
+    }
+    if (f.antialiasing) {
+        uint32_t r = 0, dim = 0;
+        rt_rng_key key;
+        key.kp = key_kp[0][threadIdx.x];
+        key.ks = key_ks[0][threadIdx.x];
+        while (r < owned) {
+            const float r1 = rt_rng_uniform(key, dim);
+            bool accept = false;
+            if (r1 >= 0.77f) {
+                const float r2 = rt_rng_uniform(key, dim + 1);
+                const float radius = __builtin_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1)); // -2 ln 2 * log2(r1)
+                const float m = fmaxf(fabsf(radius * __builtin_amdgcn_cosf(r2)), fabsf(radius * __builtin_amdgcn_sinf(r2))); // argument in turns
+                if (m < 0.4999f) {
+                    accept = true;
+                } else if (!(m > 0.5001f)) {
+                    float dx, dy;
+                    jitter_exact(key, dim, dx, dy);
+                    accept = !(fabsf(dx) > 0.5f || fabsf(dy) > 0.5f);
+                }
+            }
+            if (accept) {
+                accepted[r][threadIdx.x] = dim;
+                r++;
+                dim = 0;
+                if (r < owned) {
+                    key.kp = key_kp[r][threadIdx.x];
+                    key.ks = key_ks[r][threadIdx.x];
+                }
+            } else {
+                dim += 2;
+            }
+        }
+    }
+    uint32_t n_casts = 0;
+    for (uint32_t r = 0; r < kPaths; r++) {
+        const uint32_t p = base + r * kBlock;
+        const bool alive = p < f.n_paths;
+        V3 start = mk(f.pos[0], f.pos[1], f.pos[2]);
+        V3 ray = mk(0.f, 0.f, 1.f);
+        if (alive) {
+            const uint32_t pixel = path_pixel(f, p);
+            const uint32_t ux = pixel % f.width, uy = pixel / f.width;
+            uint32_t dim = 0;
+            float dx = 0.f, dy = 0.f;
+            if (f.antialiasing) {
+                rt_rng_key key;
+                key.kp = key_kp[r][threadIdx.x];
+                key.ks = key_ks[r][threadIdx.x];
+                dim = accepted[r][threadIdx.x];
+                jitter_exact(key, dim, dx, dy);
+                dim += 2;
+            }
+            const float px = (float)ux + 0.5f + dx;
+            const float py = (float)uy + 0.5f + dy;
+            const V3 dir = normalize(mk((px - f.cx) / f.fx, (py - f.cy) / f.fy, 1.f));
+            ray = mk(dot(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
+                     dot(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
+                     dot(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
+            w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
+            w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
+        }
+        launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
+        n_casts += (uint32_t)__popcll(__ballot(alive));
+    }
+    if (f.count_casts) add_casts(w, 0, n_casts);
+}
+
+// Adds the light contributions a path left pending at its previous hit, in
+// light order, now that k_mesh has answered its shadow rays.
+__device__ __forceinline__ V3 settle_pending(const DeviceScene& sc, const Work& w, uint32_t n_paths, uint32_t p, V3 L) {
+    for (uint32_t l = 0; l < sc.n_lights; l++) {
+        const float4 pe = w.pend[(size_t)p * sc.n_lights + l];
+        if (pe.w == PEND_NONE) continue;
+        bool visible = true;
+        if (pe.w != PEND_ALWAYS) {
+            const unsigned long long key = w.hit[(size_t)n_paths + (size_t)p * sc.n_lights + l];
+            visible = !(__uint_as_float((uint32_t)(key >> 32)) < pe.w);
+        }
+        if (visible) L = L + mk(pe.x, pe.y, pe.z);
+    }
+    return L;
+}
+
+// cosine-weighted direction about N (reference random_cos,
+// src/raytrace.cu:253-296, with argmin_abs of include/vector.cuh:87-98: the
+// running minimum starts at the signed first component)
+__device__ __forceinline__ V3 random_cos(float r1, float r2, V3 N) {
+    const float tmp1 = sqrtf(1 - r2);
+    const float tmp2 = (float)(2 * M_PI * (double)r1);
+    float sn, cs;
+    rt_sincosf(tmp2, &sn, &cs);
+    const float x = tmp1 * cs;
+    const float y = tmp1 * sn;
+    const float z = sqrtf(r2);
+    const float n[3] = {N.x, N.y, N.z};
+    float m = n[0];
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        if (fabsf(n[i]) < m) { m = fabsf(n[i]); k = i; }
+    V3 T1;
+    if (k == 0) T1 = mk(0.f, N.z, -N.y);       // (i, j) = (1, 2)
+    else if (k == 1) T1 = mk(-N.z, 0.f, N.x);  // (i, j) = (2, 0)
+    else T1 = mk(N.y, -N.x, 0.f);              // (i, j) = (0, 1)
+    T1 = normalize(T1);
+    const V3 T2 = normalize(cross(N, T1));
+    return (x * T1 + y * T2) + z * N;
+}
+
+__device__ __forceinline__ V3 reflect(V3 ray, V3 N) { return ray - (2 * dot(ray, N)) * N; }
+
+// One bounce of every live path (reference get_color loop body,
+// src/raytrace.cu:317-442).  `depth` is the bounce index; counter depth+1
+// receives the rays this bounce queues for k_mesh.
+//
+// The kernel has two parts.  The first, divergent by material, finds the hit
+// point, its normal and the bounce ray.  The second is shared by all lanes:
+// the sphere scans and box tests of the shadow rays (diffuse hits) and of the
+// bounce ray.  The first light's shadow ray and the bounce ray of a diffuse
+// hit leave the same point, so their scans run as one (nearest_sphere_pair).
+// (At least five wavefronts per SIMD: 96 VGPRs.  One register more would cost a fifth of the occupancy.)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
+    __shared__ float4 sphere_lds[kSphereCache];
+    const Spheres sp = stage_spheres(sc, sphere_lds);
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t counter = (uint32_t)depth + 1u;
+    bool alive = false; // the path continues with a bounce ray
+    bool lit = false;   // diffuse hit: the lights are evaluated at `start`
+    bool open = false;  // the path was alive on entry: its radiance record is rewritten
+    V3 start = mk(0, 0, 0), ray = mk(0, 0, 1);
+    V3 P = mk(0, 0, 0), N = mk(0, 0, 1), L = mk(0, 0, 0);
+    V3 weight = mk(0, 0, 0), colour = mk(0, 0, 0); // path weight before this hit, surface colour
+    uint32_t flags = 0;
+    if (p < f.n_paths) {
+        const float4 rad = w.rad[p];
+        flags = __float_as_uint(rad.w);
+        if (flags & F_ALIVE) {
+            open = true;
+            L = mk(rad.x, rad.y, rad.z);
+            if (flags & F_PENDING) {
+                L = settle_pending(sc, w, f.n_paths, p, L);
+                flags &= ~F_PENDING;
+            }
+            const float4 ro4 = w.ray_o[p], rd4 = w.ray_d[p];
+            start = xyz(ro4);
+            ray = xyz(rd4);
+            const float ts = ro4.w;
+            int sid = __float_as_int(rd4.w);
+            const unsigned long long key = w.hit[p];
+            const float tt = __uint_as_float((uint32_t)(key >> 32));
+            int tid = (int)(uint32_t)key; // 0xffffffff -> -1
+
+            // nearer of the two, spheres win ties (reference get_intersection,
+            // src/raytrace.cu:194-215; `tmp` starts as the triangle id)
+            float min_dist = INFINITY;
+            int tmp = tid;
+            if (ts < min_dist) { min_dist = ts; tmp = tid; tid = -1; }
+            if (tt < min_dist) { min_dist = tt; sid = -1; tid = tmp; }
+
+            if (sid >= 0 || tid >= 0) {
+                P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : start + min_dist * ray;
+                int m;
+                if (sid >= 0) {
+                    m = sc.sphere_mat[sid];
+                    N = normalize(P - xyz(sp[(uint32_t)sid]));
+                } else {
+                    float alpha, beta, gamma;
+                    barycentrics(sc, tid, ray, start, alpha, beta, gamma);
+                    const float4 s0 = sc.tri_shade[3 * tid + 0], s1 = sc.tri_shade[3 * tid + 1], s2 = sc.tri_shade[3 * tid + 2];
+                    m = __float_as_int(s0.w);
+                    N = normalize((alpha * xyz(s0) + beta * xyz(s1)) + gamma * xyz(s2));
+                }
+                const float4 mc = sc.mat_color[m];
+                const int type = __float_as_int(mc.w);
+                colour = xyz(mc);
+                const float4 th = w.thr[p];
+                weight = xyz(th);
+                V3 next_weight = weight;
+                uint32_t dim = __float_as_uint(th.w);
+                const rt_rng_key rng = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
+                alive = true;
+
+                if (type == RT_DIFFUSE) {
+                    if (!f.indirect && depth == 0) flags |= F_EARLY;
+                    if (f.antialiasing) flags &= ~F_EARLY;
+                    lit = true;
+                    start = P + scale_d(0.01, N);
+                    if (!f.indirect) {
+                        alive = false;
+                    } else {
+                        next_weight = weight * colour;
+                        const float r1 = rt_rng_uniform(rng, dim);
+                        const float r2 = rt_rng_uniform(rng, dim + 1);
+                        dim += 2;
+                        ray = random_cos(r1, r2, N);
+                    }
+                } else if (type == RT_MIRROR) {
+                    const V3 rr = reflect(ray, N);
+                    start = P + scale_d(0.01, N);
+                    ray = rr;
+                } else { // RT_GLASS
+                    const float2 ior = sc.mat_ior[m];
+                    float ro = ior.x, ri = ior.y;
+                    float wn = dot(ray, N);
+                    // Schlick reflectance (reference src/raytrace.cu:388-394)
+                    const float k0 = (ro - ri) * (ro - ri) / ((ro + ri) * (ro + ri));
+                    const float om = 1.f - fabsf(wn);
+                    const float om2 = om * om;
+                    const float R = k0 + (1.f - k0) * om2 * om2 * om;
+                    const float r = rt_rng_uniform(rng, dim);
+                    dim += 1;
+                    if (r < R) {
+                        const V3 rr = reflect(ray, N);
+                        start = P + scale_d(0.01, N);
+                        ray = rr;
+                    } else {
+                        if (wn > 0) { // leaving the medium: swap indices, flip the normal
+                            const float sw = ro; ro = ri; ri = sw;
+                            N = -1.f * N;
+                            wn = dot(ray, N);
+                        }
+                        const float eta = ro / ri;
+                        const float k = 1.f - eta * eta * (1.f - wn * wn);
+                        if (k < 0) { // total internal reflection
+                            const V3 rr = reflect(ray, N);
+                            start = P + scale_d(0.01, N);
+                            ray = rr;
+                        } else {
+                            const V3 wt_t = eta * (ray - wn * N);
+                            const V3 wt_n = (-sqrtf(k)) * N;
+                            start = P - scale_d(0.01, N);
+                            ray = wt_t + wt_n;
+                        }
+                    }
+                }
+                if (depth + 1 >= f.max_depth) alive = false;
+                w.thr[p] = make_float4(next_weight.x, next_weight.y, next_weight.z, __uint_as_float(dim));
+            }
+        }
+    }
+
+    // ---- shared part: shadow rays of diffuse hits, then the bounce ray ----
+    float ts = INFINITY;
+    int sid = -1;
+    bool walk = false;
+    bool bounce_probed = false;
+    bool deferred = false;
+    for (uint32_t l = 0; l < sc.n_lights; l++) {
+        // Direct light (reference src/raytrace.cu:351-360) and its shadow ray
+        // (is_visible, src/raytrace.cu:218-244).  Lanes without a diffuse hit
+        // carry placeholders and are masked by `lit`.
+        const float4 li = sc.light[l];
+        const V3 lp = xyz(li);
+        const V3 sp_ = lp - P;
+        const float d = norm(sp_);
+        const V3 wi = (1.f / d) * sp_;
+        const float nwi = fmaxf(dot(N, wi), 0.f);
+        const V3 sray = normalize(lp - start);
+        const float dist = norm(lp - start);
+        float ds = INFINITY;
+        int shadow_sid = -1;
+        bool shadow_walk = false;
+        if (l == 0) {
+            nearest_sphere_pair(sp, start, lit, sray, ds, shadow_sid, alive, ray, ts, sid);
+            needs_mesh_pair(sc, f.bounding_box, start, lit && !(ds < dist), sray, shadow_walk, alive, ray, walk);
+            bounce_probed = true;
+        } else if (lit) {
+            ds = nearest_sphere(sp, sray, start, shadow_sid);
+            shadow_walk = !(ds < dist) && needs_mesh(sc, f.bounding_box, sray, start);
+        }
+        const size_t slot = (size_t)p * sc.n_lights + l;
+        if (lit) {
+            const bool blocked = ds < dist;
+            // ((I / (4 pi^2 d^2) * colour) * visible) * N.wi, the first
+            // factor in double (reference src/raytrace.cu:360)
+            const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
+            const V3 direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
+            const V3 c = weight * direct;
+            if (shadow_walk) {
+                if (!deferred) // first pending light: clear the earlier slots
+                    for (uint32_t e = 0; e < l; e++) w.pend[(size_t)p * sc.n_lights + e].w = PEND_NONE;
+                deferred = true;
+                w.pend[slot] = make_float4(c.x, c.y, c.z, dist);
+                w.hit[(size_t)f.n_paths + slot] = kNoHit;
+            } else if (deferred) {
+                w.pend[slot] = make_float4(c.x, c.y, c.z, PEND_ALWAYS);
+            } else {
+                L = L + c;
+            }
+        }
+        enqueue(w, counter, lit && shadow_walk, start, sray, (uint32_t)(f.n_paths + slot), dist);
+    }
+    if (f.count_casts)
+        add_casts(w, counter, (uint32_t)__popcll(__ballot(lit)) * sc.n_lights + (uint32_t)__popcll(__ballot(alive)));
+    if (deferred) flags |= F_PENDING;
+    if (open) {
+        if (!alive) flags &= ~F_ALIVE;
+        w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
+    }
+    if (!bounce_probed && alive) { // a scene without lights
+        ts = nearest_sphere(sp, ray, start, sid);
+        walk = needs_mesh(sc, f.bounding_box, ray, start);
+    }
+    commit_ray(w, counter, alive, p, start, ray, ts, sid, walk);
+}
+
+// Per pixel: add the batch's sample colours to the running sum in sample
+// order, as the reference's sample loop does (src/raytrace.cu:478-499).
+// sum[pixel] = (r, g, b, actual_rays).
+__global__ __launch_bounds__(kBlock) void k_accumulate(DeviceScene sc, Work w, Frame f, float4* __restrict__ sum) {
+    const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
+    if (pixel >= f.n_pixels) return;
+    float4 acc = sum[f.pixel_offset + pixel];
+    const uint32_t n_samples = f.n_paths / f.n_pixels;
+    for (uint32_t s = 0; s < n_samples; s++) {
+        const uint32_t p = s * f.n_pixels + pixel;
+        const float4 rad = w.rad[p];
+        const uint32_t flags = __float_as_uint(rad.w);
+        V3 L = mk(rad.x, rad.y, rad.z);
+        if (flags & F_PENDING) L = settle_pending(sc, w, f.n_paths, p, L);
+        acc.x += L.x;
+        acc.y += L.y;
+        acc.z += L.z;
+        acc.w += 1.f;
+        if (!f.indirect && (flags & F_EARLY)) break;
+    }
+    sum[f.pixel_offset + pixel] = acc;
+}
+
+// gamma((1/actual_rays) * colour) (reference src/raytrace.cu:44-51,500)
+__global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ sum, uint32_t n_pixels, float* __restrict__ out) {
+    const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
+    if (pixel >= n_pixels) return;
+    const float4 s = sum[pixel];
+    const float inv = 1.f / s.w;
+    out[3 * pixel + 0] = rt_gamma_encode(inv * s.x);
+    out[3 * pixel + 1] = rt_gamma_encode(inv * s.y);
+    out[3 * pixel + 2] = rt_gamma_encode(inv * s.z);
+}
+
+// ------------------------------------------- known-answer test kernels
+
+// rays -> state + queue, through the same launch_ray the renderer uses
+__global__ __launch_bounds__(kBlock) void k_probe_rays(DeviceScene sc, Work w, Frame f, const float* __restrict__ origins,
+                                                       const float* __restrict__ dirs, int as_segments) {
+    __shared__ float4 sphere_lds[kSphereCache];
+    const Spheres sp = stage_spheres(sc, sphere_lds);
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    const bool alive = p < f.n_paths;
+    V3 start = mk(0, 0, 0), ray = mk(0, 0, 1);
+    if (alive) {
+        start = mk(origins[3 * p], origins[3 * p + 1], origins[3 * p + 2]);
+        ray = mk(dirs[3 * p], dirs[3 * p + 1], dirs[3 * p + 2]);
+        if (as_segments) { // `dirs` holds targets (reference is_visible)
+            const V3 target = ray;
+            ray = normalize(target - start);
+            w.thr[p] = make_float4(norm(target - start), 0.f, 0.f, 0.f);
+        }
+    }
+    launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
+}
+
+__global__ __launch_bounds__(kBlock) void k_probe_results(DeviceScene sc, Work w, Frame f, int as_segments, float* __restrict__ out_t,
+                                                          int32_t* __restrict__ out_sphere, int32_t* __restrict__ out_triangle,
+                                                          float* __restrict__ out_abg, int32_t* __restrict__ out_visible) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= f.n_paths) return;
+    const float4 ro4 = w.ray_o[p], rd4 = w.ray_d[p];
+    const float ts = ro4.w;
+    int sid = __float_as_int(rd4.w);
+    const unsigned long long key = w.hit[p];
+    const float tt = __uint_as_float((uint32_t)(key >> 32));
+    int tid = (int)(uint32_t)key;
+    if (as_segments) {
+        const float dist = w.thr[p].x;
+        out_visible[p] = (ts < dist || tt < dist) ? 0 : 1;
+        return;
+    }
+    float min_dist = INFINITY;
+    int tmp = tid;
+    if (ts < min_dist) { min_dist = ts; tmp = tid; tid = -1; }
+    if (tt < min_dist) { min_dist = tt; sid = -1; tid = tmp; }
+    out_t[p] = min_dist;
+    out_sphere[p] = sid;
+    out_triangle[p] = tid;
+    if (tid >= 0) {
+        float a, b, g;
+        barycentrics(sc, tid, xyz(rd4), xyz(ro4), a, b, g);
+        out_abg[3 * p] = a; out_abg[3 * p + 1] = b; out_abg[3 * p + 2] = g;
+    }
+}
+
+} // namespace
