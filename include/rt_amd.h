@@ -103,7 +103,11 @@ typedef struct rt_stats {
     uint64_t sphere_casts;     /* rays tested against every sphere: camera, bounce and shadow rays */
 } rt_stats;
 
-typedef struct rt_scene rt_scene; /* device-resident scene */
+/* Device-resident scene plus the work buffers of the frames rendered from it.
+ * One handle serves one frame at a time (calls on a handle must not overlap,
+ * from host threads or on different streams); independent handles -- also of
+ * the same scene -- can render concurrently on different streams. */
+typedef struct rt_scene rt_scene;
 
 /* Selects the HIP device this thread renders on (hipSetDevice). */
 int rt_init(int32_t device);
