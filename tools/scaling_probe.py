@@ -48,11 +48,12 @@ def main():
             t0 = time.perf_counter()
             for _ in range(frames):
                 step()
+            submit_ms = (time.perf_counter() - t0) / frames * 1e3  # host time to queue a frame
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / frames * 1e3
             label = overlapped if isinstance(overlapped, str) else ("overlapped" if overlapped else "serial")
             out[f"share_1_of_{n}_{label.replace(' ', '_')}_ms"] = ms
-            print(f"share 1/{n} ({r.s_end - r.s_begin} spp) {label:11s}: {ms:.3f} ms/frame", flush=True)
+            print(f"share 1/{n} ({r.s_end - r.s_begin} spp) {label:11s}: {ms:.3f} ms/frame (host queues a frame in {submit_ms:.3f} ms)", flush=True)
     print(json.dumps(out))
     dist.destroy_process_group()
 
