@@ -529,20 +529,19 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
     if (row_end < row_begin || row_end > cam->height) { rt_set_error("rt_accumulate_rows: rows [%u, %u) of %u", row_begin, row_end, cam->height); return RT_ERR_INVALID; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Frame f = make_frame(cam, opt);
-    f.n_pixels = (row_end - row_begin) * cam->width;
-    f.pixel_offset = row_begin * cam->width;
     if (stats) std::memset(stats, 0, sizeof *stats);
-    if (f.n_pixels == 0) return RT_OK;
-    const uint32_t n_pixels = f.n_pixels;
     const uint32_t n_samples = sample_end - sample_begin;
-    if (stats) std::memset(stats, 0, sizeof *stats);
-    if (n_samples == 0) return RT_OK;
-
-    uint32_t per_batch = kMaxPathsPerBatch / n_pixels;
+    if (row_end == row_begin || n_samples == 0) return RT_OK;
+    // A batch is at most 2^24 paths: a band of more pixels than that is rendered in chunks of rows,
+    // and a chunk in batches of samples.
+    const uint32_t rows_per_chunk = std::max(1u, std::min(row_end - row_begin, kMaxPathsPerBatch / cam->width));
+    const uint32_t chunk_pixels = rows_per_chunk * cam->width;
+    uint32_t per_batch = kMaxPathsPerBatch / chunk_pixels;
     if (per_batch == 0) per_batch = 1;
     if (per_batch > n_samples) per_batch = n_samples;
     const uint32_t n_counters = (uint32_t)opt->max_depth + 1u;
-    if ((rc = ensure_work(s, per_batch * n_pixels, n_counters)) != RT_OK) return rc;
+    if ((rc = ensure_work(s, per_batch * chunk_pixels, n_counters)) != RT_OK) return rc;
+    const uint64_t total_paths = (uint64_t)n_samples * (row_end - row_begin) * cam->width;
 
     const bool profile = stats && opt->profile;
     f.count_casts = stats != nullptr;
@@ -561,7 +560,11 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
     uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
     uint32_t batches = 0;
 
+    for (uint32_t chunk_row = row_begin; chunk_row < row_end; chunk_row += rows_per_chunk)
     for (uint32_t first = 0; first < n_samples; first += per_batch) {
+        const uint32_t n_pixels = std::min(rows_per_chunk, row_end - chunk_row) * cam->width;
+        f.n_pixels = n_pixels;
+        f.pixel_offset = chunk_row * cam->width;
         const uint32_t in_batch = (n_samples - first < per_batch) ? n_samples - first : per_batch;
         f.n_paths = in_batch * n_pixels;
         f.sample_begin = sample_begin + first;
@@ -589,7 +592,7 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
         paths += f.n_paths;
         if (s->progress) {
             HIP_TRY(hipStreamSynchronize(stream));
-            s->progress(paths, (uint64_t)n_samples * n_pixels, s->progress_user);
+            s->progress(paths, total_paths, s->progress_user);
         }
         if (stats) { // the counters are reused by the next batch: read them now
             HIP_TRY(hipMemcpyAsync(counts.data(), s->w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -107,6 +107,14 @@ def test_c5_default_two_lights_3000x2000():
     assert st.batches >= 2 and st.paths == 3000 * 2000 * 24
 
 
+def test_image_of_more_pixels_than_a_batch_holds():
+    """6000 x 3000 = 18 M pixels > 2^24 paths per batch: the frame is rendered in chunks of rows."""
+    s = load("mesh_scene", 6000, 3000, 2)
+    img, st = check_subset(s, rt.make_options(seed=4), 1200)
+    assert st.paths == 6000 * 3000 * 2 and st.batches == 4  # two chunks of rows x two samples
+    assert img.shape == (3000, 6000, 3)
+
+
 def test_two_lights_with_mesh_keeps_light_order():
     """Shadow rays of two lights are answered later by the triangle kernel; the
     contributions must still be added in light order."""
