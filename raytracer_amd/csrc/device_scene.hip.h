@@ -23,9 +23,8 @@ constexpr uint32_t kCastShards = 1024;      // statistics counters per path kern
 constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none)
 constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
 constexpr uint32_t kMaxLights = 64;
-constexpr uint32_t kClusterPairs = 32;      // triangle pairs per culling cluster (64 triangles)
-constexpr uint32_t kGroupClusters = 64;     // clusters per group (second level of the culling hierarchy)
-constexpr uint32_t kMaxClusters = kGroupClusters * 64; // 4096 clusters = 262 144 triangles; larger meshes get larger clusters
+constexpr uint32_t kClusterPairs = 16;      // triangle pairs per culling cluster (32 triangles; swept 4-32 on the cat mesh)
+constexpr uint32_t kMaxClusters = 64 * 64;  // two levels of at most 64 boxes each; larger meshes get larger clusters
 constexpr size_t kClusterListBudget = size_t(24) << 30; // most bytes the per-cluster ray lists may take (of 288 GB)
 
 constexpr uint32_t F_ALIVE = 1u;   // the path still bounces
@@ -49,13 +48,13 @@ struct DeviceScene {
                               // (triangles are stored in Morton order of their centroids)
     const float2* cl_pair;    // padded bounds of each cluster of cluster_pairs consecutive pairs,
                               // 6 per PAIR of clusters (2k, 2k+1): lo.x lo.y lo.z hi.x hi.y hi.z
-    const float2* grp_pair;   // the same for groups of kGroupClusters consecutive clusters (meshes of more than 64 clusters)
+    const float2* grp_pair;   // the same for groups of group_clusters consecutive clusters (meshes of more than 64 clusters)
     const float4* tri_shade;  // 3 per triangle: n0.xyz material | n1.xyz - | n2.xyz -
     const float4* box_min;
     const float4* box_max;
     const float4* light;      // position.xyz, intensity
     uint32_t n_spheres, n_triangles, n_boxes, n_lights;
-    uint32_t n_clusters, cluster_pairs, n_groups;
+    uint32_t n_clusters, cluster_pairs, n_groups, group_clusters;
 };
 
 // Per-batch path state and queues.

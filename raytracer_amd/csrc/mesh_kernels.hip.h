@@ -239,11 +239,12 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
 // per cluster, the queued rays that do; k_mesh_clusters turns the list lengths
 // into job offsets (plan_jobs) and runs the same pair scan as k_mesh over each
 // cluster's list.  A mesh of more than 64 clusters gets a second level: groups
-// of 64 consecutive clusters (neighbours in space, the triangles being in
-// Morton order) with the union of their bounds; k_bin64 lists the rays per
-// group and k_bin_groups bins each group's list into its clusters, so a ray
-// is tested against 64 boxes per level instead of against every cluster --
-// a 64-ary bounding-volume hierarchy walked breadth first.  The image is the exhaustive scan's, bit for bit, unless the
+// of about sqrt(n) consecutive clusters (neighbours in space, the triangles
+// being in Morton order; at most 64 groups of at most 64) with the union of
+// their bounds; k_bin64 lists the rays per group and k_bin_groups bins each
+// group's list into its clusters, so a ray is tested against the groups and
+// the clusters of the groups it enters instead of against every cluster -- a
+// two-level bounding-volume hierarchy walked breadth first.  The image is the exhaustive scan's, bit for bit, unless the
 // reference's own rounding makes it accept a triangle for a ray that misses
 // the triangle by more than the padding (a grazing ray whose barycentrics are
 // rounding noise); rt_options.cluster_culling = 0 selects the exhaustive scan.
@@ -259,19 +260,20 @@ __device__ __forceinline__ uint32_t owner_of_job(const uint32_t* first, uint32_t
     return lo;
 }
 
-// first_job[i] = number of 256-entry jobs of the lists before list i,
+// first_job[i] = number of jobs (of job_entries list entries) of the lists before list i,
 // first_job[n] = their total, from the list lengths (count[i * kCountStride]);
 // n <= kMaxClusters.  Every workgroup of a kernel that walks the lists makes
 // its own copy in LDS (`scan` is kBlock words of scratch): the lengths sit in
 // L2 and the scan is a few microseconds, less than a launch of its own would
 // cost.  All threads of the workgroup must call it.
-__device__ __forceinline__ void plan_jobs(const uint32_t* __restrict__ count, uint32_t n, uint32_t* first_job, uint32_t* scan) {
+__device__ __forceinline__ void plan_jobs(const uint32_t* __restrict__ count, uint32_t n, uint32_t* first_job, uint32_t* scan,
+                                          uint32_t job_entries = kBlock) {
     const uint32_t t = threadIdx.x;
     const uint32_t per = (n + kBlock - 1) / kBlock; // consecutive lists per thread, at most 16
     uint32_t mine = 0;
     for (uint32_t k = 0; k < per; k++) {
         const uint32_t i = t * per + k;
-        if (i < n) mine += (count[(size_t)i * kCountStride] + kBlock - 1) / kBlock;
+        if (i < n) mine += (count[(size_t)i * kCountStride] + job_entries - 1) / job_entries;
     }
     scan[t] = mine;
     __syncthreads();
@@ -286,7 +288,7 @@ __device__ __forceinline__ void plan_jobs(const uint32_t* __restrict__ count, ui
         const uint32_t i = t * per + k;
         if (i < n) {
             first_job[i] = run;
-            run += (count[(size_t)i * kCountStride] + kBlock - 1) / kBlock;
+            run += (count[(size_t)i * kCountStride] + job_entries - 1) / job_entries;
         }
     }
     if (t == kBlock - 1) first_job[n] = scan[t];
@@ -433,25 +435,31 @@ __global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ box_pai
 }
 
 // Second level: the rays on each group's list against the (at most 64)
-// clusters of that group.  A job is 256 list entries of one group.
-__global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl_pair, uint32_t n_clusters, uint32_t n_groups,
+// clusters of that group.  A job is R x 256 list entries of one group (R rays per lane).
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl_pair, uint32_t n_clusters, uint32_t n_groups, uint32_t group_clusters,
                                                        const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                        const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_list,
                                                        uint32_t* __restrict__ cl_count, uint32_t* __restrict__ cl_list, uint32_t list_capacity) {
     __shared__ uint32_t slot[64];
     __shared__ uint32_t first_job[64 + 1];
     __shared__ uint32_t scan[kBlock];
-    plan_jobs(grp_count, n_groups, first_job, scan);
+    plan_jobs(grp_count, n_groups, first_job, scan, R * kBlock);
     const uint32_t n_jobs = first_job[n_groups];
     for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
         const uint32_t g = owner_of_job(first_job, n_groups, job);
         const uint32_t count = grp_count[g * kCountStride];
-        const uint32_t e = (job - first_job[g]) * kBlock + threadIdx.x;
-        const bool active[1] = {e < count};
-        const uint32_t at[1] = {grp_list[(size_t)g * list_capacity + (active[0] ? e : count - 1)]};
-        const uint32_t first_cluster = g * kGroupClusters;
-        bin_rays64<1>(cl_pair + 6 * (size_t)(first_cluster / 2), min(kGroupClusters, n_clusters - first_cluster), active, at, q_o, q_d,
-                   cl_count + (size_t)first_cluster * kCountStride, cl_list + (size_t)first_cluster * list_capacity, list_capacity, slot);
+        bool active[R];
+        uint32_t at[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const uint32_t e = ((job - first_job[g]) * R + i) * kBlock + threadIdx.x;
+            active[i] = e < count;
+            at[i] = grp_list[(size_t)g * list_capacity + (active[i] ? e : count - 1)];
+        }
+        const uint32_t first_cluster = g * group_clusters; // even: a group starts a box pair
+        bin_rays64<R>(cl_pair + 6 * (size_t)(first_cluster / 2), min(group_clusters, n_clusters - first_cluster), active, at, q_o, q_d,
+                      cl_count + (size_t)first_cluster * kCountStride, cl_list + (size_t)first_cluster * list_capacity, list_capacity, slot);
     }
 }
 

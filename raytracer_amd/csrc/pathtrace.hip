@@ -284,7 +284,8 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
                 hipLaunchKernelGGL(bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
                                    tile * blocks_per_tile, blocks_per_tile, grp_count, s->w.grp_list, s->w.list_capacity);
-                hipLaunchKernelGGL(k_bin_groups, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc, ng,
+                auto bin_groups = wide ? k_bin_groups<2> : k_bin_groups<1>;
+                hipLaunchKernelGGL(bin_groups, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc, ng, s->d.group_clusters,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)grp_count,
                                    (const uint32_t*)s->w.grp_list, cl_count, s->w.cl_list, s->w.list_capacity);
             }
@@ -448,12 +449,18 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
             if (c & 1) dst.y = v[k]; else dst.x = v[k];
         }
     }
-    // groups of kGroupClusters consecutive clusters with the union of their bounds
-    const uint32_t n_groups = n_clusters > 64 ? (n_clusters + kGroupClusters - 1) / kGroupClusters : 0;
+    // groups of consecutive clusters with the union of their bounds: about sqrt(n) groups of
+    // sqrt(n) clusters (an even number, so that a group starts a box pair), at most 64 of at most 64
+    uint32_t group_clusters = 2 * (((uint32_t)std::ceil(std::sqrt((double)n_clusters)) + 1) / 2);
+    if (const char* env = std::getenv("RT_AMD_GROUP_CLUSTERS")) { // tuning / test knob
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 2 && v <= 64 && v % 2 == 0 && (n_clusters + v - 1) / v <= 64) group_clusters = (uint32_t)v;
+    }
+    const uint32_t n_groups = n_clusters > 64 ? (n_clusters + group_clusters - 1) / group_clusters : 0;
     std::vector<float2> grp_pair(6 * (((size_t)n_groups + 1) / 2), make_float2(0.f, 0.f));
     for (uint32_t g = 0; g < n_groups; g++) {
         float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t c = g * kGroupClusters; c < std::min(n_clusters, (g + 1) * kGroupClusters); c++) {
+        for (uint32_t c = g * group_clusters; c < std::min(n_clusters, (g + 1) * group_clusters); c++) {
             const float lo[3] = {cl_min[c].x, cl_min[c].y, cl_min[c].z}, hi[3] = {cl_max[c].x, cl_max[c].y, cl_max[c].z};
             for (int a = 0; a < 3; a++) {
                 if (lo[a] < v[a]) v[a] = lo[a];
@@ -481,6 +488,7 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     s->d.n_clusters = n_clusters;
     s->d.cluster_pairs = cluster_pairs;
     s->d.n_groups = n_groups;
+    s->d.group_clusters = group_clusters;
     s->cluster_tris = cluster_tris;
     if ((rc = upload(s, sphere, &s->d.sphere)) || (rc = upload(s, sphere_mat, &s->d.sphere_mat)) ||
         (rc = upload(s, mat_color, &s->d.mat_color)) || (rc = upload(s, mat_ior, &s->d.mat_ior)) ||
