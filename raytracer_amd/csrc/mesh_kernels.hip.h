@@ -349,32 +349,43 @@ __device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint3
     }
 }
 
-// Bins R rays per lane (queue positions at[i], ignored when !active[i])
-// against up to 64 padded boxes and appends each position to the list of every
-// box its ray enters before its cut-off distance.  One pass over the boxes: a
-// lane keeps the boxes a ray touches as a 64-bit mask; then every lane walks
-// the set bits of its masks twice -- to count per box in LDS (`slot`, 64
-// words), and, after the workgroup has reserved list space with one atomic per
-// box, to take its positions.  All threads of the workgroup must call it.
-template <int R>
-__device__ __forceinline__ void bin_prepared64(const f2* __restrict__ box_pair, uint32_t n_boxes, const bool (&active)[R], const uint32_t (&at)[R],
-                                               const SlabRay (&ray)[R], uint32_t* __restrict__ count, uint32_t* __restrict__ list,
-                                               uint32_t list_capacity, uint32_t* slot) {
-    if (threadIdx.x < 64) slot[threadIdx.x] = 0;
-    __syncthreads();
+// The boxes (up to 64, as a bit mask) that S rays per lane enter before their
+// cut-off distances; the rays are read from the queue at positions at[i] and
+// a ray with !active[i] gets an empty mask.  The box data of an iteration
+// (scalar loads) serves all S rays.
+template <int S>
+__device__ __forceinline__ void touched_boxes(const f2* __restrict__ box_pair, uint32_t n_boxes, const bool* active, const uint32_t* at,
+                                              const float4* __restrict__ q_o, const float4* __restrict__ q_d, unsigned long long* mine) {
+    SlabRay ray[S];
+#pragma unroll
+    for (int i = 0; i < S; i++) ray[i] = slab_ray(q_o[at[i]], q_d[at[i]]);
     const uint32_t n_pairs = (n_boxes + 1) / 2;
-    // boxes 0-31 and 32-63 each ray touches
-    uint32_t bits_lo[R], bits_hi[R];
-    slab_bits<R>(box_pair, 0, min(n_pairs, 16u), ray, bits_lo);
-    slab_bits<R>(box_pair, 16, max(n_pairs, 16u), ray, bits_hi);
+    uint32_t bits_lo[S], bits_hi[S]; // boxes 0-31 and 32-63
+    slab_bits<S>(box_pair, 0, min(n_pairs, 16u), ray, bits_lo);
+    slab_bits<S>(box_pair, 16, max(n_pairs, 16u), ray, bits_hi);
     // an odd box count leaves the second half of the last entry without a box: drop its bit
     const unsigned long long real = n_boxes >= 64 ? ~0ULL : (1ULL << n_boxes) - 1ULL;
-    unsigned long long mine[R];
 #pragma unroll
-    for (int i = 0; i < R; i++) {
-        mine[i] = active[i] ? ((((unsigned long long)bits_hi[i] << 32) | bits_lo[i]) & real) : 0ULL;
+    for (int i = 0; i < S; i++) mine[i] = active[i] ? ((((unsigned long long)bits_hi[i] << 32) | bits_lo[i]) & real) : 0ULL;
+}
+
+// Appends R queue positions per lane to the lists of the boxes in their masks:
+// every lane walks the set bits of its masks twice -- to count per box in LDS
+// (`slot`, 64 words), and, after the workgroup has reserved list space with ONE
+// global atomic per box, to take its positions.  The reservations are what
+// bounds the binning kernels: a counter sustains only 100-200 atomics per
+// microsecond, so the more rays a workgroup brings per reservation, the better
+// (as long as enough workgroups stay busy).  All threads of the workgroup must
+// call it.
+template <int R>
+__device__ __forceinline__ void append_to_lists(uint32_t n_boxes, const unsigned long long (&mine)[R], const uint32_t (&at)[R],
+                                                uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity,
+                                                uint32_t* slot) {
+    if (threadIdx.x < 64) slot[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R; i++)
         for (unsigned long long m = mine[i]; m; m &= m - 1) atomicAdd(&slot[(uint32_t)__ffsll((long long)m) - 1u], 1u);
-    }
     __syncthreads();
     if (threadIdx.x < n_boxes) {
         const uint32_t total = slot[threadIdx.x];
@@ -390,23 +401,28 @@ __device__ __forceinline__ void bin_prepared64(const f2* __restrict__ box_pair, 
     __syncthreads();
 }
 
-// The same for rays read back from the queue.
+// Bins R rays per lane (R = 1 or a multiple of 2; slab tests two rays at a time).
 template <int R>
 __device__ __forceinline__ void bin_rays64(const f2* __restrict__ box_pair, uint32_t n_boxes, const bool (&active)[R], const uint32_t (&at)[R],
                                            const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                            uint32_t* __restrict__ count, uint32_t* __restrict__ list, uint32_t list_capacity,
                                            uint32_t* slot) {
-    SlabRay ray[R];
+    unsigned long long mine[R];
+    if constexpr (R == 1) {
+        touched_boxes<1>(box_pair, n_boxes, active, at, q_o, q_d, mine);
+    } else {
+        static_assert(R % 2 == 0, "rays per lane: 1 or even");
 #pragma unroll
-    for (int i = 0; i < R; i++) ray[i] = slab_ray(q_o[at[i]], q_d[at[i]]);
-    bin_prepared64<R>(box_pair, n_boxes, active, at, ray, count, list, list_capacity, slot);
+        for (int i = 0; i < R; i += 2) touched_boxes<2>(box_pair, n_boxes, active + i, at + i, q_o, q_d, mine + i);
+    }
+    append_to_lists<R>(n_boxes, mine, at, count, list, list_capacity, slot);
 }
 
 // First level: the queued rays of one tile (256-ray blocks [first_block,
 // first_block + blocks_in_tile)) against the clusters of a mesh of at most 64
 // clusters, or against the groups of a larger one.  A workgroup takes R
-// consecutive ray blocks at a time (R rays per lane): two halve the barriers
-// and reservations per ray, one keeps more workgroups busy when the queue is
+// consecutive ray blocks at a time (R rays per lane) and reserves list space
+// once for all of them; fewer keep more workgroups busy when the queue is
 // short.
 template <int R>
 __global__ __launch_bounds__(kBlock) void k_bin64(const f2* __restrict__ box_pair, uint32_t n_boxes,

@@ -273,7 +273,8 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
             const f2* cl_pair = reinterpret_cast<const f2*>(s->d.cl_pair);
             // two ray blocks per workgroup, except for short batches (measured: better from about 2 M paths up)
             const bool wide = batch_paths >= 1536u * 1024u;
-            auto bin64 = wide ? k_bin64<2> : k_bin64<1>;
+            const bool wider = batch_paths >= 6u * 1024u * 1024u;
+            auto bin64 = wider ? k_bin64<4> : wide ? k_bin64<2> : k_bin64<1>;
             if (s->d.n_groups == 0) {
                 hipLaunchKernelGGL(bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
@@ -284,7 +285,7 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
                 hipLaunchKernelGGL(bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
                                    tile * blocks_per_tile, blocks_per_tile, grp_count, s->w.grp_list, s->w.list_capacity);
-                auto bin_groups = wide ? k_bin_groups<2> : k_bin_groups<1>;
+                auto bin_groups = wider ? k_bin_groups<4> : wide ? k_bin_groups<2> : k_bin_groups<1>;
                 hipLaunchKernelGGL(bin_groups, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc, ng, s->d.group_clusters,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)grp_count,
                                    (const uint32_t*)s->w.grp_list, cl_count, s->w.cl_list, s->w.list_capacity);
