@@ -94,6 +94,9 @@ class Meter:
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
             "traffic": traffic,
+            # the same launch against the other roofline: measured HBM bytes per launch (PMC, profiles/) over its duration
+            "hbm_gbps": (traffic / (self.mesh_ms / self.launches * 1e-3) / 1e9) if traffic and self.launches and self.mesh_ms > 0 else None,
+            "hbm_peak_gbps": 8000.0,
             "avg_launch_ms": self.mesh_ms / self.launches if self.launches else None,
             "launches_per_step": self.launches / max(self.frames, 1),
             "triangle_tests_per_step": self.tests / max(self.frames, 1),
