@@ -65,8 +65,11 @@ struct Work {
     float4* rad;     // colour L.xyz, F_* flags as uint bits
     float4* pend;    // n_lights per path: contribution.xyz, light distance or PEND_*
     unsigned long long* hit; // paths + paths*n_lights slots: (t bits << 32) | triangle
-    float4* q_o;     // queued ray origin.xyz, hit slot as uint bits
-    float4* q_d;     // queued ray direction.xyz, cut-off distance
+    // the ray queue: 32-byte records (origin.xyz, hit slot as uint bits | direction.xyz, cut-off
+    // distance), so that a gather through a cluster list touches one line per ray;
+    // entry i is q_o[2 i] and q_d[2 i], with q_d = q_o + 1
+    float4* q_o;
+    float4* q_d;
     uint32_t* q_count; // kShards counters (kCountStride words apart) per k_mesh stage of a batch
     uint32_t* cast_count; // statistics: kCastShards counters (kCountStride words apart) per path kernel of a batch
     uint32_t shard_capacity; // queue entries reserved per shard
@@ -235,8 +238,8 @@ __device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, boo
     uint32_t at = 0;
     if (want) {
         at = shard * w.shard_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
-        w.q_o[at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot));
-        w.q_d[at] = make_float4(ray.x, ray.y, ray.z, cutoff);
+        w.q_o[2 * (size_t)at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot));
+        w.q_d[2 * (size_t)at] = make_float4(ray.x, ray.y, ray.z, cutoff);
     }
     return at;
 }

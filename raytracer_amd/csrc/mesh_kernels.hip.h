@@ -218,8 +218,8 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
         const uint32_t chunk = q % n_chunks;
         bool active;
         const uint32_t at = ray_position(map, ray_block, shard_capacity, active);
-        const float4 o4 = q_o[at];
-        const float4 d4 = q_d[at];
+        const float4 o4 = q_o[2 * (size_t)at];
+        const float4 d4 = q_d[2 * (size_t)at];
         Nearest best = nearest_init(d4.w);
         const uint32_t first = chunk * kChunkPairs;
         scan_pairs(tri2, tri_orig, first, min(first + kChunkPairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
@@ -358,7 +358,7 @@ __device__ __forceinline__ void touched_boxes(const f2* __restrict__ box_pair, u
                                               const float4* __restrict__ q_o, const float4* __restrict__ q_d, unsigned long long* mine) {
     SlabRay ray[S];
 #pragma unroll
-    for (int i = 0; i < S; i++) ray[i] = slab_ray(q_o[at[i]], q_d[at[i]]);
+    for (int i = 0; i < S; i++) ray[i] = slab_ray(q_o[2 * (size_t)at[i]], q_d[2 * (size_t)at[i]]);
     const uint32_t n_pairs = (n_boxes + 1) / 2;
     uint32_t bits_lo[S], bits_hi[S]; // boxes 0-31 and 32-63
     slab_bits<S>(box_pair, 0, min(n_pairs, 16u), ray, bits_lo);
@@ -496,8 +496,8 @@ __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__
         const uint32_t e = (job - first_job[c]) * kBlock + threadIdx.x;
         const bool active = e < count;
         const uint32_t at = cl_list[(size_t)c * list_capacity + (active ? e : count - 1)];
-        const float4 o4 = q_o[at];
-        const float4 d4 = q_d[at];
+        const float4 o4 = q_o[2 * (size_t)at];
+        const float4 d4 = q_d[2 * (size_t)at];
         Nearest best = nearest_init(d4.w);
         const uint32_t first = c * cluster_pairs;
         scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);

@@ -206,7 +206,7 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     if ((rc = work_alloc(s, &s->w.ray_o, n_paths)) || (rc = work_alloc(s, &s->w.ray_d, n_paths)) ||
         (rc = work_alloc(s, &s->w.thr, n_paths)) || (rc = work_alloc(s, &s->w.rad, n_paths)) ||
         (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
-        (rc = work_alloc(s, &s->w.q_o, queue_entries)) || (rc = work_alloc(s, &s->w.q_d, queue_entries)) ||
+        (rc = work_alloc(s, &s->w.q_o, 2 * queue_entries)) ||
         (rc = work_alloc(s, &s->w.q_count, q_words + cl_words + grp_words)) || // one block: cleared with one fill
         (rc = work_alloc(s, &s->w.cast_count, (size_t)n_counters * kCastShards * kCountStride)) ||
         (rc = work_alloc(s, &s->w.cl_list, nc * list_capacity)) ||
@@ -214,6 +214,7 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
         free_work(s);
         return rc;
     }
+    s->w.q_d = s->w.q_o + 1;
     s->w.cl_count = s->w.q_count + q_words;
     s->w.grp_count = s->w.cl_count + cl_words;
     s->counter_words = q_words + cl_words + grp_words;
