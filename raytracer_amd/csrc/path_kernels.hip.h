@@ -19,6 +19,8 @@ struct Frame {
     uint32_t seed;
     int32_t indirect, antialiasing, bounding_box, max_depth;
     int32_t count_casts;    // count the rays tested against the spheres (statistics)
+    int32_t skip_dark_shadows; // shadow rays of zero contributions do not walk the mesh (not in the exhaustive mode,
+                               // which keeps the reference's amount of work)
 };
 
 __device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return f.pixel_offset + p % f.n_pixels; }
@@ -377,6 +379,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
             const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
             const V3 direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
             const V3 c = weight * direct;
+            // A contribution of exactly zero (light behind the surface, black surface) is the
+            // same added or not: what the triangles would say about its shadow ray does not
+            // matter.  (L is a sum of non-negative terms, never -0, so L + 0 has L's bits.)
+            if (f.skip_dark_shadows && c.x == 0.f && c.y == 0.f && c.z == 0.f) shadow_walk = false;
             if (shadow_walk) {
                 if (!deferred) // first pending light: clear the earlier slots
                     for (uint32_t e = 0; e < l; e++) w.pend[(size_t)p * sc.n_lights + e].w = PEND_NONE;

@@ -242,6 +242,7 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     f.bounding_box = opt->bounding_box != 0;
     f.max_depth = opt->max_depth;
     f.count_casts = 0;
+    f.skip_dark_shadows = 0;
     return f;
 }
 
@@ -556,6 +557,7 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
     const bool profile = stats && opt->profile;
     f.count_casts = stats != nullptr;
     const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
+    f.skip_dark_shadows = opt->cluster_culling != 0;
     const size_t cl_words = cull ? (size_t)n_counters * s->tiles * s->d.n_clusters * kCountStride : 0;
     std::vector<uint32_t> cl_counts(cl_words);
     uint64_t tests = 0;

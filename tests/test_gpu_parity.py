@@ -130,7 +130,9 @@ def test_culled_and_exhaustive_frames_are_identical_at_full_size():
     print(f"culled {sa.triangle_tests / sa.paths:.0f} vs exhaustive {sb.triangle_tests / sb.paths:.0f} triangle tests per path; "
           f"{differing} of {a.shape[0] * a.shape[1]} pixels differ")
     assert differing == 0
-    assert sa.mesh_rays == sb.mesh_rays
+    # the default mode also drops the mesh walk of shadow rays whose contribution is exactly zero
+    print(f"mesh rays: culled mode {sa.mesh_rays}, exhaustive mode {sb.mesh_rays}")
+    assert 0.5 * sb.mesh_rays < sa.mesh_rays < sb.mesh_rays
     assert sa.triangle_tests < 0.35 * sb.triangle_tests
 
 
