@@ -79,6 +79,11 @@ struct Work {
     uint32_t* grp_count;     // the same three for the groups of clusters
     uint32_t* grp_list;
     uint32_t list_capacity;  // = rays binned per tile
+    // the paths that are still alive, for the next bounce: kShards shards like the ray queue,
+    // two buffers (bounce d reads buffer d & 1 and fills the other)
+    uint32_t* live;
+    uint32_t* live_count;    // kShards counters per bounce
+    uint32_t live_capacity;  // path indices reserved per shard
 };
 
 struct V3 {
@@ -242,6 +247,21 @@ __device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, boo
         w.q_d[2 * (size_t)at] = make_float4(ray.x, ray.y, ray.z, cutoff);
     }
     return at;
+}
+
+// Appends the path indices of the lanes with want == true to the list of live
+// paths that bounce `counter` will read; shards and counters as in enqueue.
+__device__ __forceinline__ void append_live(const Work& w, uint32_t counter, bool want, uint32_t p) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&w.live_count[(counter * kShards + shard) * kCountStride], (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (want)
+        w.live[((size_t)(counter & 1u) * kShards + shard) * w.live_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL))] = p;
 }
 
 // Statistics: adds n (the wavefront's number of rays tested against the

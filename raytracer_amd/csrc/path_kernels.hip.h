@@ -19,8 +19,9 @@ struct Frame {
     uint32_t seed;
     int32_t indirect, antialiasing, bounding_box, max_depth;
     int32_t count_casts;    // count the rays tested against the spheres (statistics)
-    int32_t skip_dark_shadows; // shadow rays of zero contributions do not walk the mesh (not in the exhaustive mode,
-                               // which keeps the reference's amount of work)
+    int32_t prune_zero_terms; // work whose result can only add exact zeros is dropped: the mesh walk of a shadow
+                              // ray with a zero contribution, the rest of a path whose weight is zero (not in
+                              // the exhaustive mode, which keeps the reference's amount of work)
 };
 
 __device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return f.pixel_offset + p % f.n_pixels; }
@@ -224,8 +225,17 @@ __device__ __forceinline__ V3 reflect(V3 ray, V3 N) { return ray - (2 * dot(ray,
 // (At least five wavefronts per SIMD: 96 VGPRs.  One register more would cost a fifth of the occupancy.)
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
     __shared__ float4 sphere_lds[kSphereCache];
+    // The first bounce sees every path; later ones walk the list of paths the previous bounce
+    // left alive, so that the lanes of a wavefront are all busy however many paths have ended.
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (depth > 0) {
+        const ShardMap map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
+        if (blockIdx.x >= map.n_ray_blocks) return; // the whole workgroup
+        bool active;
+        const uint32_t at = ray_position(map, blockIdx.x, w.live_capacity, active);
+        p = active ? w.live[(size_t)(depth & 1) * kShards * w.live_capacity + at] : 0xffffffffu;
+    }
     const Spheres sp = stage_spheres(sc, sphere_lds);
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t counter = (uint32_t)depth + 1u;
     bool alive = false; // the path continues with a bounce ray
     bool lit = false;   // diffuse hit: the lights are evaluated at `start`
@@ -337,6 +347,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                     }
                 }
                 if (depth + 1 >= f.max_depth) alive = false;
+                // A weight of exactly zero in all three channels (a pure red wall seen from a pure
+                // green one) stays zero, and every later term of the path is weight * direct light
+                // with a finite direct light: the path has nothing more to add.
+                if (f.prune_zero_terms && next_weight.x == 0.f && next_weight.y == 0.f && next_weight.z == 0.f) alive = false;
                 w.thr[p] = make_float4(next_weight.x, next_weight.y, next_weight.z, __uint_as_float(dim));
             }
         }
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
             // A contribution of exactly zero (light behind the surface, black surface) is the
             // same added or not: what the triangles would say about its shadow ray does not
             // matter.  (L is a sum of non-negative terms, never -0, so L + 0 has L's bits.)
-            if (f.skip_dark_shadows && c.x == 0.f && c.y == 0.f && c.z == 0.f) shadow_walk = false;
+            if (f.prune_zero_terms && c.x == 0.f && c.y == 0.f && c.z == 0.f) shadow_walk = false;
             if (shadow_walk) {
                 if (!deferred) // first pending light: clear the earlier slots
                     for (uint32_t e = 0; e < l; e++) w.pend[(size_t)p * sc.n_lights + e].w = PEND_NONE;
@@ -409,6 +423,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
         walk = needs_mesh(sc, f.bounding_box, ray, start);
     }
     commit_ray(w, counter, alive, p, start, ray, ts, sid, walk);
+    append_live(w, counter, alive, p);
 }
 
 // Per pixel: add the batch's sample colours to the running sum in sample

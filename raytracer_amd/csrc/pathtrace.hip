@@ -177,7 +177,9 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t nl = s->d.n_lights ? s->d.n_lights : 1;
     const size_t slots = (size_t)n_paths * (1 + nl);
     // a shard receives the rays of every kShards-th wavefront of a path kernel
-    const size_t n_waves = (((size_t)n_paths + kBlock - 1) / kBlock) * kWavesPerBlock;
+    // (k_shade walks its list of live paths shard by shard, every shard ending in a partial workgroup:
+    // up to kShards workgroups more than the paths need)
+    const size_t n_waves = (((size_t)n_paths + kBlock - 1) / kBlock + kShards) * kWavesPerBlock;
     // k_shade: a wavefront queues at most 64 * (1 + lights) rays; k_generate: 64 * kGenPaths, from fewer wavefronts
     size_t shard_capacity = ((n_waves + kShards - 1) / kShards) * 64 * (1 + nl);
     for (size_t r = 2; r <= kGenPaths; r *= 2) {
@@ -202,12 +204,14 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t slots_cl = (size_t)n_counters * tiles;
     const size_t q_words = (size_t)n_counters * kShards * kCountStride;
     const size_t cl_words = slots_cl * nc * kCountStride, grp_words = slots_cl * ng * kCountStride;
+    const size_t live_capacity = ((n_waves + kShards - 1) / kShards) * 64; // a wavefront keeps at most its 64 paths
     int rc;
     if ((rc = work_alloc(s, &s->w.ray_o, n_paths)) || (rc = work_alloc(s, &s->w.ray_d, n_paths)) ||
         (rc = work_alloc(s, &s->w.thr, n_paths)) || (rc = work_alloc(s, &s->w.rad, n_paths)) ||
         (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
         (rc = work_alloc(s, &s->w.q_o, 2 * queue_entries)) ||
-        (rc = work_alloc(s, &s->w.q_count, q_words + cl_words + grp_words)) || // one block: cleared with one fill
+        (rc = work_alloc(s, &s->w.q_count, 2 * q_words + cl_words + grp_words)) || // one block: cleared with one fill
+        (rc = work_alloc(s, &s->w.live, 2 * kShards * live_capacity)) ||
         (rc = work_alloc(s, &s->w.cast_count, (size_t)n_counters * kCastShards * kCountStride)) ||
         (rc = work_alloc(s, &s->w.cl_list, nc * list_capacity)) ||
         (rc = work_alloc(s, &s->w.grp_list, ng * list_capacity))) {
@@ -215,9 +219,11 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
         return rc;
     }
     s->w.q_d = s->w.q_o + 1;
-    s->w.cl_count = s->w.q_count + q_words;
+    s->w.live_count = s->w.q_count + q_words;
+    s->w.cl_count = s->w.live_count + q_words;
     s->w.grp_count = s->w.cl_count + cl_words;
-    s->counter_words = q_words + cl_words + grp_words;
+    s->counter_words = 2 * q_words + cl_words + grp_words;
+    s->w.live_capacity = (uint32_t)live_capacity;
     s->w.shard_capacity = (uint32_t)shard_capacity;
     s->w.list_capacity = (uint32_t)list_capacity;
     s->tiles = (uint32_t)tiles;
@@ -242,7 +248,7 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     f.bounding_box = opt->bounding_box != 0;
     f.max_depth = opt->max_depth;
     f.count_casts = 0;
-    f.skip_dark_shadows = 0;
+    f.prune_zero_terms = 0;
     return f;
 }
 
@@ -557,7 +563,7 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
     const bool profile = stats && opt->profile;
     f.count_casts = stats != nullptr;
     const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
-    f.skip_dark_shadows = opt->cluster_culling != 0;
+    f.prune_zero_terms = opt->cluster_culling != 0;
     const size_t cl_words = cull ? (size_t)n_counters * s->tiles * s->d.n_clusters * kCountStride : 0;
     std::vector<uint32_t> cl_counts(cl_words);
     uint64_t tests = 0;
@@ -593,7 +599,7 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
             if ((rc = launch_mesh(s, (uint32_t)depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, s->d, s->w, f, depth);
+            hipLaunchKernelGGL(k_shade, depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, s->w, f, depth);
             HIP_TRY(hipGetLastError());
         }
         if ((rc = launch_mesh(s, (uint32_t)opt->max_depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
