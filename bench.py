@@ -33,6 +33,8 @@ sys.path.insert(0, ROOT)
 # ray-triangle test (3 vector subtractions, 2 cross products, 3 dot products,
 # 2 divisions, 1 negation, 2 subtractions; reference src/raytrace.cu:155-164).
 FLOP_PER_TRIANGLE_TEST = 47
+FLOP_PER_SPHERE_TEST = 19
+FLOP_PER_BOX_TEST = 22
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X fp32 vector peak (packed FMA)
 # the reference's published time for this configuration: 53.77 s on a GTX 1050
 # (reference README.md:78) = 512*512*32 / 53.77 paths per second
@@ -72,8 +74,8 @@ class Meter:
     """Sums the per-frame kernel statistics of the timed steps."""
 
     def __init__(self):
-        self.mesh_ms = self.bin_ms = 0.0
-        self.launches = self.tests = self.frames = 0
+        self.mesh_ms = self.bin_ms = self.shade_ms = 0.0
+        self.launches = self.tests = self.frames = self.shade_launches = self.casts = 0
 
     def add(self, st):
         if st is None:
@@ -82,6 +84,9 @@ class Meter:
         self.bin_ms += st.bin_kernel_ms
         self.launches += st.mesh_kernel_launches
         self.tests += st.triangle_tests
+        self.shade_ms += st.shade_kernel_ms
+        self.shade_launches += st.shade_kernel_launches
+        self.casts += st.sphere_casts
         self.frames += 1
 
     def roofline(self, kernel, step_ms, traffic):
@@ -104,6 +109,31 @@ class Meter:
             "binning_ms_per_step": self.bin_ms / max(self.frames, 1),
         }
 
+    def shade_roofline(self, step_ms, n_spheres, n_boxes, generate_casts_per_frame, traffic):
+        """The bounce kernel against the same VALU peak.  Algorithmic work = the sphere scans and box
+        tests of the rays it casts (19 flop per ray-sphere test, 22 per ray-box test, the reference's
+        formulation, src/raytrace.cu:53-146); the shading arithmetic itself is not counted."""
+        if not self.shade_launches or self.shade_ms <= 0:
+            return None
+        casts = self.casts - generate_casts_per_frame * self.frames  # camera rays are cast by k_generate
+        flop = casts * (FLOP_PER_SPHERE_TEST * n_spheres + FLOP_PER_BOX_TEST * n_boxes)
+        achieved = flop / (self.shade_ms * 1e-3) / 1e12
+        return {
+            "bound": "valu",
+            "kernel": "k_shade",
+            "achieved": achieved,
+            "peak": PEAK_FP32_VECTOR_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+            "traffic": traffic,
+            "hbm_gbps": traffic / (self.shade_ms / self.shade_launches * 1e-3) / 1e9 if traffic else None,
+            "hbm_peak_gbps": 8000.0,
+            "avg_launch_ms": self.shade_ms / self.shade_launches,
+            "launches_per_step": self.shade_launches / max(self.frames, 1),
+            "casts_per_step": casts / max(self.frames, 1),
+            "kernel_share_of_step": self.shade_ms / max(self.frames, 1) / step_ms if step_ms else None,
+        }
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -113,7 +143,7 @@ def main():
     ap.add_argument("--scene", default="mesh_scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exhaustive", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
+    ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="frames a rank keeps in flight, each on its own stream and scene handle (1 = one after the other)")
     args = ap.parse_args()
 
@@ -163,7 +193,7 @@ def main():
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
-            # Steps just enqueue: consecutive frames overlap on the device (two streams), and with
+            # Steps just enqueue: consecutive frames overlap on the device (a stream per frame in flight), and with
             # N > 1 so do the all-reduce of one frame and the kernels of the next.  Every 16th step
             # is a sampling step: the device is drained first, so that the frame runs alone and the
             # HIP events around its triangle kernels time them undisturbed; its counters are read back.
@@ -227,6 +257,9 @@ def main():
             # over their summed duration, from HIP events on the launch stream.
             "roofline": meter.roofline("k_mesh_clusters", ms_per_step, traffic.get("k_mesh_clusters_hbm_bytes_per_launch")),
         }
+        # the other large kernel of the default mode (about half of the frame since the culling)
+        line["roofline_k_shade"] = meter.shade_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes), n_pixels * spp,
+                                                          traffic.get("k_shade_hbm_bytes_per_launch"))
         if exhaustive is not None:
             ex_elapsed, ex_meter, ex_steps = exhaustive
             line["exhaustive_scan"] = {

@@ -83,10 +83,15 @@ typedef struct rt_options {
     uint32_t seed;
     int32_t profile;   /* non-zero: time the triangle kernel with events */
     /* 0: every queued ray is tested against every triangle, the reference's
-     * scan (src/raytrace.cu:148-175).  Non-zero: triangles are grouped into
-     * clusters of 64 neighbours and a ray skips the clusters whose padded
-     * bounds it misses.  Same image unless the reference's rounding accepts a
-     * triangle for a ray that misses it by more than the padding. */
+     * scan (src/raytrace.cu:148-175), and every path runs all its bounces.
+     * Non-zero: triangles are grouped into clusters of 32 neighbours and a ray
+     * skips the clusters whose padded bounds it misses; work that can only add
+     * exact zeros is dropped (the mesh walk of a shadow ray whose contribution
+     * is zero, the remaining bounces of a path whose weight is zero in all
+     * three channels).  Same image unless the reference's rounding accepts a
+     * triangle for a ray that misses it by more than the padding, or a path of
+     * zero weight would have met a light at distance exactly zero (the
+     * reference then adds 0 x inf = NaN). */
     int32_t cluster_culling;
 } rt_options;
 
@@ -101,6 +106,10 @@ typedef struct rt_stats {
     uint64_t mesh_rays;        /* rays that walked the triangle list           */
     uint64_t triangle_tests;   /* ray-triangle tests the triangle kernel executed */
     uint64_t sphere_casts;     /* rays tested against every sphere: camera, bounce and shadow rays */
+    double shade_kernel_ms;    /* the bounce kernel (hit selection, materials, lights, sphere scans), summed
+                                  over launches (profile != 0 only) */
+    uint32_t shade_kernel_launches;
+    uint32_t reserved;
 } rt_stats;
 
 /* Device-resident scene plus the work buffers of the frames rendered from it.

@@ -65,7 +65,8 @@ class Stats(C.Structure):
         ("gpu_ms", C.c_double), ("mesh_kernel_ms", C.c_double), ("bin_kernel_ms", C.c_double),
         ("mesh_kernel_launches", C.c_uint32), ("batches", C.c_uint32),
         ("paths", C.c_uint64), ("mesh_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
-        ("sphere_casts", C.c_uint64),
+        ("sphere_casts", C.c_uint64), ("shade_kernel_ms", C.c_double), ("shade_kernel_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

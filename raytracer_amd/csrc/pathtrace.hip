@@ -252,22 +252,24 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     return f;
 }
 
+// Profiling mark on the stream: 'B' binning starts, 'M' triangle kernel starts, 'E' it ended,
+// 'S' k_shade starts.
+int mark_event(rt_scene* s, hipStream_t stream, char tag) {
+    if (s->event_tags.size() == s->events.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        s->events.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(s->events[s->event_tags.size()], stream));
+    s->event_tags.push_back(tag);
+    return RT_OK;
+}
+
 // One k_mesh stage: the queued rays of `counter` against the mesh, either by
 // the exhaustive scan or through the cluster lists.
 int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile, bool cull, uint32_t batch_paths) {
     if (s->d.n_triangles == 0) return RT_OK;
-    // profiling marks: 'B' binning starts, 'M' triangle kernel starts, 'E' it ended
-    auto mark = [&](char tag) -> int {
-        if (!profile) return RT_OK;
-        if (s->event_tags.size() == s->events.size()) {
-            hipEvent_t e = nullptr;
-            HIP_TRY(hipEventCreate(&e));
-            s->events.push_back(e);
-        }
-        HIP_TRY(hipEventRecord(s->events[s->event_tags.size()], stream));
-        s->event_tags.push_back(tag);
-        return RT_OK;
-    };
+    auto mark = [&](char tag) -> int { return profile ? mark_event(s, stream, tag) : RT_OK; };
     int rc;
     const f2* tri2 = reinterpret_cast<const f2*>(s->d.tri_pair);
     const uint32_t* q_count = s->w.q_count + (size_t)counter * kShards * kCountStride;
@@ -599,7 +601,9 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
             if ((rc = launch_mesh(s, (uint32_t)depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
+            if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
             hipLaunchKernelGGL(k_shade, depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, s->w, f, depth);
+            if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
         }
         if ((rc = launch_mesh(s, (uint32_t)opt->max_depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
@@ -640,6 +644,9 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
             HIP_TRY(hipEventElapsedTime(&k, s->events[i], s->events[i + 1]));
             if (s->event_tags[i] == 'B') {
                 stats->bin_kernel_ms += k;
+            } else if (s->event_tags[i] == 'S') {
+                stats->shade_kernel_ms += k;
+                stats->shade_kernel_launches++;
             } else {
                 stats->mesh_kernel_ms += k;
                 stats->mesh_kernel_launches++;
