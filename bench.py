@@ -257,8 +257,11 @@ def main():
             # over their summed duration, from HIP events on the launch stream.
             "roofline": meter.roofline("k_mesh_clusters", ms_per_step, traffic.get("k_mesh_clusters_hbm_bytes_per_launch")),
         }
+        from raytracer_amd.distributed import sample_range
+        begin, end = sample_range(0, world, spp)  # rank 0's share (the statistics are rank 0's)
+        own_samples = end - begin
         # the other large kernel of the default mode (about half of the frame since the culling)
-        line["roofline_k_shade"] = meter.shade_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes), n_pixels * spp,
+        line["roofline_k_shade"] = meter.shade_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes), n_pixels * own_samples,
                                                           traffic.get("k_shade_hbm_bytes_per_launch"))
         if exhaustive is not None:
             ex_elapsed, ex_meter, ex_steps = exhaustive
