@@ -27,6 +27,8 @@ constexpr uint32_t kClusterPairs = 16;      // triangle pairs per culling cluste
 constexpr uint32_t kMaxClusters = 64 * 64;  // two levels of at most 64 boxes each; larger meshes get larger clusters
 constexpr size_t kClusterListBudget = size_t(24) << 30; // most bytes the per-cluster ray lists may take (of 288 GB)
 
+constexpr uint32_t kLivePending = 0x80000000u; // in an entry of the live-path list: the path has F_PENDING set
+
 constexpr uint32_t F_ALIVE = 1u;   // the path still bounces
 constexpr uint32_t F_PENDING = 2u; // pend[] holds light contributions of the last hit
 constexpr uint32_t F_EARLY = 4u;   // the reference's terminate_early for this sample
@@ -53,7 +55,7 @@ struct DeviceScene {
     const float4* box_min;
     const float4* box_max;
     const float4* light;      // position.xyz, intensity
-    uint32_t n_spheres, n_triangles, n_boxes, n_lights;
+    uint32_t n_spheres, n_triangles, n_boxes, n_lights, n_materials;
     uint32_t n_clusters, cluster_pairs, n_groups, group_clusters;
 };
 
@@ -121,30 +123,92 @@ __device__ __forceinline__ V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
 
 // ---------------------------------------------------------- intersection
 
-// The first kSphereCache spheres of the scene, staged in LDS by the kernels
-// that test every sphere for every path: the index is wave-uniform, so an LDS
-// read is a broadcast, whereas a global load (which the compiler cannot turn
-// into a scalar load in kernels that also write global memory) stalls every
-// iteration on the vector memory path.
-constexpr uint32_t kSphereCache = 64;
+// Scene data that every path reads with wave-uniform or small indices, staged
+// in LDS by the path kernels.  An LDS read is a broadcast of about a hundred
+// cycles; a global load in the middle of a kernel (which the compiler cannot
+// turn into a scalar load in kernels that also write global memory) is a round
+// trip to L2, and the few resident wavefronts of these register-heavy kernels
+// cannot hide a dozen of those in a row.  Entries beyond the cached counts are
+// read from global memory.
+constexpr uint32_t kSphereCache = 64, kMatCache = 128, kLightCache = 8, kBoxCache = 8;
 
-struct Spheres {
-    const float4* lds;
-    const float4* global;
-    uint32_t cached, n;
-    __device__ __forceinline__ float4 operator[](uint32_t i) const { return i < cached ? lds[i] : global[i]; }
+struct SceneCache {
+    float4 sphere[kSphereCache];
+    float4 mat_color[kMatCache];
+    float2 mat_ior[kMatCache];
+    int32_t sphere_mat[kSphereCache];
+    float4 light[kLightCache];
+    float4 box_min[kBoxCache], box_max[kBoxCache];
 };
 
-// All threads of the workgroup must call it.
-__device__ __forceinline__ Spheres stage_spheres(const DeviceScene& sc, float4* lds) {
-    Spheres s;
-    s.lds = lds;
-    s.global = sc.sphere;
-    s.n = sc.n_spheres;
-    s.cached = s.n < kSphereCache ? s.n : kSphereCache;
-    for (uint32_t i = threadIdx.x; i < s.cached; i += kBlock) lds[i] = sc.sphere[i];
+// All threads of the workgroup must call it.  Every thread copies at most one entry of one
+// array, so the whole cache costs one round trip to memory.
+static_assert(kSphereCache + kMatCache + kLightCache + kBoxCache <= kBlock, "one thread per cached entry");
+__device__ __forceinline__ void stage_scene(const DeviceScene& sc, SceneCache& c) {
+    uint32_t i = threadIdx.x;
+    if (i < kSphereCache) {
+        if (i < sc.n_spheres) {
+            c.sphere[i] = sc.sphere[i];
+            c.sphere_mat[i] = sc.sphere_mat[i];
+        }
+    } else if ((i -= kSphereCache) < kMatCache) {
+        if (i < sc.n_materials) {
+            c.mat_color[i] = sc.mat_color[i];
+            c.mat_ior[i] = sc.mat_ior[i];
+        }
+    } else if ((i -= kMatCache) < kLightCache) {
+        if (i < sc.n_lights) c.light[i] = sc.light[i];
+    } else if ((i -= kLightCache) < kBoxCache) {
+        if (i < sc.n_boxes) {
+            c.box_min[i] = sc.box_min[i];
+            c.box_max[i] = sc.box_max[i];
+        }
+    }
     __syncthreads();
-    return s;
+}
+
+// Single entries: the LDS read is unconditional (index wrapped into the cache) and the rare entry
+// beyond the cache replaces it, so that the common case is a plain LDS read.
+__device__ __forceinline__ float4 sphere_at(const DeviceScene& sc, const SceneCache& c, uint32_t i) {
+    float4 v = c.sphere[i % kSphereCache];
+    if (i >= kSphereCache) v = sc.sphere[i];
+    return v;
+}
+__device__ __forceinline__ int sphere_material(const DeviceScene& sc, const SceneCache& c, uint32_t i) {
+    int v = c.sphere_mat[i % kSphereCache];
+    if (i >= kSphereCache) v = sc.sphere_mat[i];
+    return v;
+}
+__device__ __forceinline__ float4 material_color(const DeviceScene& sc, const SceneCache& c, uint32_t m) {
+    float4 v = c.mat_color[m % kMatCache];
+    if (m >= kMatCache) v = sc.mat_color[m];
+    return v;
+}
+__device__ __forceinline__ float2 material_ior(const DeviceScene& sc, const SceneCache& c, uint32_t m) {
+    float2 v = c.mat_ior[m % kMatCache];
+    if (m >= kMatCache) v = sc.mat_ior[m];
+    return v;
+}
+__device__ __forceinline__ float4 light_at(const DeviceScene& sc, const SceneCache& c, uint32_t l) {
+    float4 v = c.light[l % kLightCache];
+    if (l >= kLightCache) v = sc.light[l];
+    return v;
+}
+
+// body(i, sphere i) for every sphere in index order: the cached ones from LDS, the rest from global memory.
+template <typename Body>
+__device__ __forceinline__ void for_each_sphere(const DeviceScene& sc, const SceneCache& c, Body&& body) {
+    const uint32_t cached = min(sc.n_spheres, kSphereCache);
+    for (uint32_t i = 0; i < cached; i++) body(i, c.sphere[i]);
+    for (uint32_t i = cached; i < sc.n_spheres; i++) body(i, sc.sphere[i]);
+}
+
+// body(box_min o, box_max o) for every object box in index order.
+template <typename Body>
+__device__ __forceinline__ void for_each_box(const DeviceScene& sc, const SceneCache& c, Body&& body) {
+    const uint32_t cached = min(sc.n_boxes, kBoxCache);
+    for (uint32_t o = 0; o < cached; o++) body(c.box_min[o], c.box_max[o]);
+    for (uint32_t o = cached; o < sc.n_boxes; o++) body(sc.box_min[o], sc.box_max[o]);
 }
 
 // One sphere of the reference's scan (get_distance, src/raytrace.cu:59-84)
@@ -163,32 +227,30 @@ __device__ __forceinline__ void sphere_step(float b, float n2, float R, uint32_t
 }
 
 // Nearest sphere along a ray (reference get_distance, src/raytrace.cu:53-87).
-__device__ __forceinline__ float nearest_sphere(const Spheres& sp, V3 ray, V3 start, int& id) {
+__device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start, int& id) {
     float min_dist = INFINITY;
-    for (uint32_t i = 0; i < sp.n; i++) {
-        const float4 s = sp[i];
+    for_each_sphere(sc, c, [&](uint32_t i, float4 s) {
         const V3 oc = start - xyz(s);
         const float ocn = norm(oc);
         sphere_step(dot(ray, oc), ocn * ocn, s.w, i, min_dist, id);
-    }
+    });
     return min_dist;
 }
 
 // The same scan for two rays that leave the same point (a shadow ray and the
 // bounce ray of one hit): OC and its norm depend on the start only and are
 // computed once per sphere.  A ray whose flag is false keeps (inf, id).
-__device__ __forceinline__ void nearest_sphere_pair(const Spheres& sp, V3 start, bool do_a, V3 ray_a, float& dist_a, int& id_a,
-                                                    bool do_b, V3 ray_b, float& dist_b, int& id_b) {
+__device__ __forceinline__ void nearest_sphere_pair(const DeviceScene& sc, const SceneCache& c, V3 start, bool do_a, V3 ray_a,
+                                                    float& dist_a, int& id_a, bool do_b, V3 ray_b, float& dist_b, int& id_b) {
     dist_a = INFINITY;
     dist_b = INFINITY;
-    for (uint32_t i = 0; i < sp.n; i++) {
-        const float4 s = sp[i];
+    for_each_sphere(sc, c, [&](uint32_t i, float4 s) {
         const V3 oc = start - xyz(s);
         const float ocn = norm(oc);
         const float n2 = ocn * ocn;
         if (do_a) sphere_step(dot(ray_a, oc), n2, s.w, i, dist_a, id_a);
         if (do_b) sphere_step(dot(ray_b, oc), n2, s.w, i, dist_b, id_b);
-    }
+    });
 }
 
 // One box of the scan below for a ray, given lo = box_min - start, hi = box_max - start.
@@ -219,10 +281,12 @@ __device__ __forceinline__ bool box_hit(V3 lo, V3 hi, V3 ray) {
 // src/raytrace.cu:103-145): per axis the entry/exit parameters stay 0 when
 // the ray is parallel to the slab, there is no t > 0 requirement, and the
 // verdict is min(exit) > max(entry).
-__device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, V3 ray, V3 start) {
-    for (uint32_t o = 0; o < sc.n_boxes; o++)
-        if (box_hit(xyz(sc.box_min[o]) - start, xyz(sc.box_max[o]) - start, ray)) return true;
-    return false;
+__device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start) {
+    bool hit = false;
+    for_each_box(sc, c, [&](float4 lo, float4 hi) {
+        if (!hit) hit = box_hit(xyz(lo) - start, xyz(hi) - start, ray);
+    });
+    return hit;
 }
 
 // Appends the rays of the lanes with want == true to the k_mesh queue: one
@@ -249,19 +313,37 @@ __device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, boo
     return at;
 }
 
-// Appends the path indices of the lanes with want == true to the list of live
-// paths that bounce `counter` will read; shards and counters as in enqueue.
-__device__ __forceinline__ void append_live(const Work& w, uint32_t counter, bool want, uint32_t p) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0) return;
+// The end of a bounce for a wavefront, ALL of whose lanes must call it: queues a shadow ray
+// (want_a) and the bounce ray (want_b) for triangle stage `counter`, and appends `entry` to the
+// list of live paths that bounce `counter` reads (want_live).  Both reservations are issued
+// together by lane 0, so the wavefront waits for one round trip to the counters instead of three.
+__device__ __forceinline__ void enqueue_pair_and_live(const Work& w, uint32_t counter, bool want_a, V3 start_a, V3 ray_a, uint32_t slot_a,
+                                                      float cutoff_a, bool want_b, V3 start_b, V3 ray_b, uint32_t slot_b, float cutoff_b,
+                                                      bool want_live, uint32_t entry) {
+    const unsigned long long mask_a = __ballot(want_a), mask_b = __ballot(want_b), mask_l = __ballot(want_live);
+    const uint32_t n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b), n_l = (uint32_t)__popcll(mask_l);
     const uint32_t lane = __lane_id();
     const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
-    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&w.live_count[(counter * kShards + shard) * kCountStride], (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)leader);
-    if (want)
-        w.live[((size_t)(counter & 1u) * kShards + shard) * w.live_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL))] = p;
+    uint32_t base_q = 0, base_l = 0;
+    if (lane == 0) {
+        if (n_a + n_b) base_q = atomicAdd(&w.q_count[(counter * kShards + shard) * kCountStride], n_a + n_b);
+        if (n_l) base_l = atomicAdd(&w.live_count[(counter * kShards + shard) * kCountStride], n_l);
+    }
+    base_q = __shfl(base_q, 0);
+    base_l = __shfl(base_l, 0);
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    if (want_a) {
+        const size_t at = shard * w.shard_capacity + base_q + (uint32_t)__popcll(mask_a & below);
+        w.q_o[2 * at] = make_float4(start_a.x, start_a.y, start_a.z, __uint_as_float(slot_a));
+        w.q_d[2 * at] = make_float4(ray_a.x, ray_a.y, ray_a.z, cutoff_a);
+    }
+    if (want_b) {
+        const size_t at = shard * w.shard_capacity + base_q + n_a + (uint32_t)__popcll(mask_b & below);
+        w.q_o[2 * at] = make_float4(start_b.x, start_b.y, start_b.z, __uint_as_float(slot_b));
+        w.q_d[2 * at] = make_float4(ray_b.x, ray_b.y, ray_b.z, cutoff_b);
+    }
+    if (want_live)
+        w.live[((size_t)(counter & 1u) * kShards + shard) * w.live_capacity + base_l + (uint32_t)__popcll(mask_l & below)] = entry;
 }
 
 // Statistics: adds n (the wavefront's number of rays tested against the
@@ -276,25 +358,25 @@ __device__ __forceinline__ void add_casts(const Work& w, uint32_t counter, uint3
 
 // True when the ray has to walk the triangle list (reference
 // src/raytrace.cu:103-146: with boxes enabled only after a box hit).
-__device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, int use_boxes, V3 ray, V3 start) {
+__device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, const SceneCache& c, int use_boxes, V3 ray, V3 start) {
     if (sc.n_triangles == 0) return false;
     if (!use_boxes) return true;
-    return any_box_hit(sc, ray, start);
+    return any_box_hit(sc, c, ray, start);
 }
 
 // needs_mesh for two rays that leave the same point; box - start is shared.
-__device__ __forceinline__ void needs_mesh_pair(const DeviceScene& sc, int use_boxes, V3 start, bool do_a, V3 ray_a, bool& walk_a,
-                                                bool do_b, V3 ray_b, bool& walk_b) {
+__device__ __forceinline__ void needs_mesh_pair(const DeviceScene& sc, const SceneCache& c, int use_boxes, V3 start, bool do_a, V3 ray_a,
+                                                bool& walk_a, bool do_b, V3 ray_b, bool& walk_b) {
     walk_a = false;
     walk_b = false;
     if (sc.n_triangles == 0) return;
     if (!use_boxes) { walk_a = do_a; walk_b = do_b; return; }
-    for (uint32_t o = 0; o < sc.n_boxes; o++) {
-        const V3 lo = xyz(sc.box_min[o]) - start;
-        const V3 hi = xyz(sc.box_max[o]) - start;
+    for_each_box(sc, c, [&](float4 bmin, float4 bmax) {
+        const V3 lo = xyz(bmin) - start;
+        const V3 hi = xyz(bmax) - start;
         if (do_a && !walk_a) walk_a = box_hit(lo, hi, ray_a);
         if (do_b && !walk_b) walk_b = box_hit(lo, hi, ray_b);
-    }
+    });
 }
 
 // Barycentrics of a known hit, by the expressions of the reference's triangle

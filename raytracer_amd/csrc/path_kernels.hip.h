@@ -41,14 +41,14 @@ __device__ __forceinline__ uint32_t commit_ray(const Work& w, uint32_t counter, 
 }
 
 // Nearest sphere + box test for a freshly generated ray, then commit_ray.
-__device__ __forceinline__ void launch_ray(const DeviceScene& sc, const Spheres& sp, const Work& w, const Frame& f, uint32_t counter,
+__device__ __forceinline__ void launch_ray(const DeviceScene& sc, const SceneCache& cache, const Work& w, const Frame& f, uint32_t counter,
                                            bool alive, uint32_t p, V3 start, V3 ray) {
     int sid = -1;
     float ts = INFINITY;
     bool walk = false;
     if (alive) {
-        ts = nearest_sphere(sp, ray, start, sid);
-        walk = needs_mesh(sc, f.bounding_box, ray, start);
+        ts = nearest_sphere(sc, cache, ray, start, sid);
+        walk = needs_mesh(sc, cache, f.bounding_box, ray, start);
     }
     commit_ray(w, counter, alive, p, start, ray, ts, sid, walk);
 }
@@ -84,10 +84,10 @@ __device__ __forceinline__ void jitter_exact(const rt_rng_key& key, uint32_t dim
 
 template <uint32_t kPaths>
 __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f) {
-    __shared__ float4 sphere_lds[kSphereCache];
+    __shared__ SceneCache cache;
     __shared__ uint32_t key_kp[kPaths][kBlock], key_ks[kPaths][kBlock];
     __shared__ uint32_t accepted[kPaths][kBlock]; // first dimension of the accepted draw
-    const Spheres sp = stage_spheres(sc, sphere_lds);
+    stage_scene(sc, cache);
     const uint32_t base = blockIdx.x * (kBlock * kPaths) + threadIdx.x;
     // only this lane reads what it writes to the three arrays: no barrier needed
     uint32_t owned = 0;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
             w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
         }
-        launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
+        launch_ray(sc, cache, w, f, 0, alive, p, start, ray);
         n_casts += (uint32_t)__popcll(__ballot(alive));
     }
     if (f.count_casts) add_casts(w, 0, n_casts);
@@ -171,13 +171,17 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
 
 // Adds the light contributions a path left pending at its previous hit, in
 // light order, now that k_mesh has answered its shadow rays.
-__device__ __forceinline__ V3 settle_pending(const DeviceScene& sc, const Work& w, uint32_t n_paths, uint32_t p, V3 L) {
+// (The caller may have fetched the first light's pending record and shadow result already.)
+__device__ __forceinline__ V3 settle_pending(const DeviceScene& sc, const Work& w, uint32_t n_paths, uint32_t p, V3 L,
+                                             bool have_first = false, float4 first_pend = make_float4(0, 0, 0, 0),
+                                             unsigned long long first_key = 0) {
     for (uint32_t l = 0; l < sc.n_lights; l++) {
-        const float4 pe = w.pend[(size_t)p * sc.n_lights + l];
+        const bool fetched = have_first && l == 0;
+        const float4 pe = fetched ? first_pend : w.pend[(size_t)p * sc.n_lights + l];
         if (pe.w == PEND_NONE) continue;
         bool visible = true;
         if (pe.w != PEND_ALWAYS) {
-            const unsigned long long key = w.hit[(size_t)n_paths + (size_t)p * sc.n_lights + l];
+            const unsigned long long key = fetched ? first_key : w.hit[(size_t)n_paths + (size_t)p * sc.n_lights + l];
             visible = !(__uint_as_float((uint32_t)(key >> 32)) < pe.w);
         }
         if (visible) L = L + mk(pe.x, pe.y, pe.z);
@@ -224,18 +228,23 @@ __device__ __forceinline__ V3 reflect(V3 ray, V3 N) { return ray - (2 * dot(ray,
 // hit leave the same point, so their scans run as one (nearest_sphere_pair).
 // (At least five wavefronts per SIMD: 96 VGPRs.  One register more would cost a fifth of the occupancy.)
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
-    __shared__ float4 sphere_lds[kSphereCache];
+    __shared__ SceneCache cache;
     // The first bounce sees every path; later ones walk the list of paths the previous bounce
     // left alive, so that the lanes of a wavefront are all busy however many paths have ended.
+    // A list entry is the path index, with kLivePending set when light terms of the previous
+    // hit await their shadow rays.
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    bool pending = false;
     if (depth > 0) {
         const ShardMap map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
         if (blockIdx.x >= map.n_ray_blocks) return; // the whole workgroup
         bool active;
         const uint32_t at = ray_position(map, blockIdx.x, w.live_capacity, active);
-        p = active ? w.live[(size_t)(depth & 1) * kShards * w.live_capacity + at] : 0xffffffffu;
+        const uint32_t entry = active ? w.live[(size_t)(depth & 1) * kShards * w.live_capacity + at] : 0xffffffffu;
+        p = active ? (entry & ~kLivePending) : 0xffffffffu;
+        pending = active && (entry & kLivePending) != 0;
     }
-    const Spheres sp = stage_spheres(sc, sphere_lds);
+    stage_scene(sc, cache);
     const uint32_t counter = (uint32_t)depth + 1u;
     bool alive = false; // the path continues with a bounce ray
     bool lit = false;   // diffuse hit: the lights are evaluated at `start`
@@ -245,21 +254,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     V3 weight = mk(0, 0, 0), colour = mk(0, 0, 0); // path weight before this hit, surface colour
     uint32_t flags = 0;
     if (p < f.n_paths) {
+        // the whole state of the path in one round trip to memory
         const float4 rad = w.rad[p];
+        const float4 ro4 = w.ray_o[p], rd4 = w.ray_d[p], th = w.thr[p];
+        const unsigned long long key = w.hit[p];
+        float4 first_pend = make_float4(0.f, 0.f, 0.f, PEND_NONE);
+        unsigned long long first_key = kNoHit;
+        if (pending) {
+            first_pend = w.pend[(size_t)p * sc.n_lights];
+            first_key = w.hit[(size_t)f.n_paths + (size_t)p * sc.n_lights];
+        }
         flags = __float_as_uint(rad.w);
         if (flags & F_ALIVE) {
             open = true;
             L = mk(rad.x, rad.y, rad.z);
             if (flags & F_PENDING) {
-                L = settle_pending(sc, w, f.n_paths, p, L);
+                L = settle_pending(sc, w, f.n_paths, p, L, pending, first_pend, first_key);
                 flags &= ~F_PENDING;
             }
-            const float4 ro4 = w.ray_o[p], rd4 = w.ray_d[p];
             start = xyz(ro4);
             ray = xyz(rd4);
             const float ts = ro4.w;
             int sid = __float_as_int(rd4.w);
-            const unsigned long long key = w.hit[p];
             const float tt = __uint_as_float((uint32_t)(key >> 32));
             int tid = (int)(uint32_t)key; // 0xffffffff -> -1
 
@@ -274,8 +290,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                 P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : start + min_dist * ray;
                 int m;
                 if (sid >= 0) {
-                    m = sc.sphere_mat[sid];
-                    N = normalize(P - xyz(sp[(uint32_t)sid]));
+                    m = sphere_material(sc, cache, (uint32_t)sid);
+                    N = normalize(P - xyz(sphere_at(sc, cache, (uint32_t)sid)));
                 } else {
                     float alpha, beta, gamma;
                     barycentrics(sc, tid, ray, start, alpha, beta, gamma);
@@ -283,10 +299,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                     m = __float_as_int(s0.w);
                     N = normalize((alpha * xyz(s0) + beta * xyz(s1)) + gamma * xyz(s2));
                 }
-                const float4 mc = sc.mat_color[m];
+                const float4 mc = material_color(sc, cache, (uint32_t)m);
                 const int type = __float_as_int(mc.w);
                 colour = xyz(mc);
-                const float4 th = w.thr[p];
                 weight = xyz(th);
                 V3 next_weight = weight;
                 uint32_t dim = __float_as_uint(th.w);
@@ -312,7 +327,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                     start = P + scale_d(0.01, N);
                     ray = rr;
                 } else { // RT_GLASS
-                    const float2 ior = sc.mat_ior[m];
+                    const float2 ior = material_ior(sc, cache, (uint32_t)m);
                     float ro = ior.x, ri = ior.y;
                     float wn = dot(ray, N);
                     // Schlick reflectance (reference src/raytrace.cu:388-394)
@@ -362,11 +377,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     bool walk = false;
     bool bounce_probed = false;
     bool deferred = false;
+    // the last light's shadow ray is queued together with the bounce ray
+    bool last_want = false;
+    V3 last_sray = mk(0, 0, 1);
+    float last_dist = 0.f;
+    uint32_t last_slot = 0;
     for (uint32_t l = 0; l < sc.n_lights; l++) {
         // Direct light (reference src/raytrace.cu:351-360) and its shadow ray
         // (is_visible, src/raytrace.cu:218-244).  Lanes without a diffuse hit
         // carry placeholders and are masked by `lit`.
-        const float4 li = sc.light[l];
+        const float4 li = light_at(sc, cache, l);
         const V3 lp = xyz(li);
         const V3 sp_ = lp - P;
         const float d = norm(sp_);
@@ -378,12 +398,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
         int shadow_sid = -1;
         bool shadow_walk = false;
         if (l == 0) {
-            nearest_sphere_pair(sp, start, lit, sray, ds, shadow_sid, alive, ray, ts, sid);
-            needs_mesh_pair(sc, f.bounding_box, start, lit && !(ds < dist), sray, shadow_walk, alive, ray, walk);
+            nearest_sphere_pair(sc, cache, start, lit, sray, ds, shadow_sid, alive, ray, ts, sid);
+            needs_mesh_pair(sc, cache, f.bounding_box, start, lit && !(ds < dist), sray, shadow_walk, alive, ray, walk);
             bounce_probed = true;
         } else if (lit) {
-            ds = nearest_sphere(sp, sray, start, shadow_sid);
-            shadow_walk = !(ds < dist) && needs_mesh(sc, f.bounding_box, sray, start);
+            ds = nearest_sphere(sc, cache, sray, start, shadow_sid);
+            shadow_walk = !(ds < dist) && needs_mesh(sc, cache, f.bounding_box, sray, start);
         }
         const size_t slot = (size_t)p * sc.n_lights + l;
         if (lit) {
@@ -409,7 +429,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                 L = L + c;
             }
         }
-        enqueue(w, counter, lit && shadow_walk, start, sray, (uint32_t)(f.n_paths + slot), dist);
+        if (l + 1 < sc.n_lights) {
+            enqueue(w, counter, lit && shadow_walk, start, sray, (uint32_t)(f.n_paths + slot), dist);
+        } else {
+            last_want = lit && shadow_walk;
+            last_sray = sray;
+            last_dist = dist;
+            last_slot = (uint32_t)(f.n_paths + slot);
+        }
     }
     if (f.count_casts)
         add_casts(w, counter, (uint32_t)__popcll(__ballot(lit)) * sc.n_lights + (uint32_t)__popcll(__ballot(alive)));
@@ -419,11 +446,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
         w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
     }
     if (!bounce_probed && alive) { // a scene without lights
-        ts = nearest_sphere(sp, ray, start, sid);
-        walk = needs_mesh(sc, f.bounding_box, ray, start);
+        ts = nearest_sphere(sc, cache, ray, start, sid);
+        walk = needs_mesh(sc, cache, f.bounding_box, ray, start);
     }
-    commit_ray(w, counter, alive, p, start, ray, ts, sid, walk);
-    append_live(w, counter, alive, p);
+    if (alive) { // state of the bounce ray (as commit_ray)
+        w.ray_o[p] = make_float4(start.x, start.y, start.z, ts);
+        w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
+        w.hit[p] = kNoHit;
+    }
+    enqueue_pair_and_live(w, counter, last_want, start, last_sray, last_slot, last_dist, alive && walk, start, ray, p, ts,
+                          alive, p | (deferred ? kLivePending : 0u));
 }
 
 // Per pixel: add the batch's sample colours to the running sum in sample
@@ -465,8 +497,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ s
 // rays -> state + queue, through the same launch_ray the renderer uses
 __global__ __launch_bounds__(kBlock) void k_probe_rays(DeviceScene sc, Work w, Frame f, const float* __restrict__ origins,
                                                        const float* __restrict__ dirs, int as_segments) {
-    __shared__ float4 sphere_lds[kSphereCache];
-    const Spheres sp = stage_spheres(sc, sphere_lds);
+    __shared__ SceneCache cache;
+    stage_scene(sc, cache);
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     const bool alive = p < f.n_paths;
     V3 start = mk(0, 0, 0), ray = mk(0, 0, 1);
@@ -479,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void k_probe_rays(DeviceScene sc, Work w, F
             w.thr[p] = make_float4(norm(target - start), 0.f, 0.f, 0.f);
         }
     }
-    launch_ray(sc, sp, w, f, 0, alive, p, start, ray);
+    launch_ray(sc, cache, w, f, 0, alive, p, start, ray);
 }
 
 __global__ __launch_bounds__(kBlock) void k_probe_results(DeviceScene sc, Work w, Frame f, int as_segments, float* __restrict__ out_t,

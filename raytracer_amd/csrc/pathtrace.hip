@@ -496,6 +496,7 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     s->d.n_triangles = d->n_triangles;
     s->d.n_boxes = d->n_boxes;
     s->d.n_lights = d->n_lights;
+    s->d.n_materials = d->n_materials;
     s->d.n_clusters = n_clusters;
     s->d.cluster_pairs = cluster_pairs;
     s->d.n_groups = n_groups;
