@@ -111,7 +111,22 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y
 // the same with the explicit leading zero, for the few places that divide by
 // the result of a dot with an axis vector
 __device__ __forceinline__ float dot_z(V3 a, V3 b) { return ((0.f + a.x * b.x) + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ float norm(V3 a) { return sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+// Correctly rounded square root -- the value sqrtf returns -- without the range scaling the
+// compiler wraps around every sqrtf: v_sqrt_f32 is within one unit in the last place, and the
+// exact residuals x - s * neighbour decide between s and its two neighbours.  Below 2^-96 the
+// residuals would leave the normal range, so a wavefront with such an input (zero included)
+// takes the library routine for all its lanes: both routes give the same value above it.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    if (__ballot(x < 0x1p-96f) != 0) return sqrtf(x);
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float down = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+    const float r_down = __builtin_fmaf(-down, s, x), r_up = __builtin_fmaf(-up, s, x);
+    s = r_down <= 0.f ? down : s;
+    s = r_up > 0.f ? up : s;
+    return s;
+}
+
+__device__ __forceinline__ float norm(V3 a) { return sqrt_rn((a.x * a.x + a.y * a.y) + a.z * a.z); }
 __device__ __forceinline__ V3 normalize(V3 a) {
     const float n = norm(a);
     return mk(a.x / n, a.y / n, a.z / n);
@@ -216,7 +231,7 @@ __device__ __forceinline__ void for_each_box(const DeviceScene& sc, const SceneC
 __device__ __forceinline__ void sphere_step(float b, float n2, float R, uint32_t i, float& min_dist, int& id) {
     const float delta = b * b - n2 + R * R;
     if (delta >= 0) {
-        const float sq = sqrtf(delta);
+        const float sq = sqrt_rn(delta);
         const float t2 = -b + sq;
         if (t2 >= 0) {
             const float t1 = -b - sq;

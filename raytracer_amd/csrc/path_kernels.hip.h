@@ -74,7 +74,7 @@ constexpr uint32_t kGenPaths = 4; // at most; short batches use fewer so that th
 __device__ __forceinline__ void jitter_exact(const rt_rng_key& key, uint32_t dim, float& dx, float& dy) {
     const float r1 = rt_rng_uniform(key, dim);
     const float r2 = rt_rng_uniform(key, dim + 1);
-    const float radius = sqrtf(-2 * rt_logf(r1));
+    const float radius = sqrt_rn(-2 * rt_logf(r1));
     const float angle = (float)(2 * M_PI * (double)r2);
     float sn, cs;
     rt_sincosf(angle, &sn, &cs);
@@ -193,13 +193,13 @@ __device__ __forceinline__ V3 settle_pending(const DeviceScene& sc, const Work& 
 // src/raytrace.cu:253-296, with argmin_abs of include/vector.cuh:87-98: the
 // running minimum starts at the signed first component)
 __device__ __forceinline__ V3 random_cos(float r1, float r2, V3 N) {
-    const float tmp1 = sqrtf(1 - r2);
+    const float tmp1 = sqrt_rn(1 - r2);
     const float tmp2 = (float)(2 * M_PI * (double)r1);
     float sn, cs;
     rt_sincosf(tmp2, &sn, &cs);
     const float x = tmp1 * cs;
     const float y = tmp1 * sn;
-    const float z = sqrtf(r2);
+    const float z = sqrt_rn(r2);
     const float n[3] = {N.x, N.y, N.z};
     float m = n[0];
     int k = 0;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                             ray = rr;
                         } else {
                             const V3 wt_t = eta * (ray - wn * N);
-                            const V3 wt_n = (-sqrtf(k)) * N;
+                            const V3 wt_n = (-sqrt_rn(k)) * N;
                             start = P - scale_d(0.01, N);
                             ray = wt_t + wt_n;
                         }
