@@ -268,6 +268,14 @@ __device__ __forceinline__ void nearest_sphere_pair(const DeviceScene& sc, const
     });
 }
 
+// Hardware minimum / maximum without the canonicalising extra instruction fminf / fmaxf bring.
+// (A NaN operand is dropped in favour of the other one.)
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3_abs(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // One box of the scan below for a ray, given lo = box_min - start, hi = box_max - start.
 __device__ __forceinline__ bool box_hit(V3 lo, V3 hi, V3 ray) {
     const V3 axis[3] = {mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1)};
@@ -292,14 +300,54 @@ __device__ __forceinline__ bool box_hit(V3 lo, V3 hi, V3 ray) {
     return mn > mx;
 }
 
+// The verdict of box_hit from reciprocals instead of IEEE quotients: 1 hit, 0 miss, -1 too close
+// to call.  A quotient a * rcp(r) is within 2.4e-7 (relative) of the IEEE quotient a / r, so
+// min(exit) - max(entry) is off by less than 1e-6 times the largest of the six quotients; a gap
+// larger than that has the sign the exact arithmetic gives it.  Non-finite inputs or quotients
+// make the band NaN or infinite and so end in "too close to call", which the caller answers with
+// box_hit.  finite_probe is any sum over the components of lo and hi (NaN or inf if one of them is).
+__device__ __forceinline__ int box_verdict(V3 lo, V3 hi, V3 ray, float finite_probe) {
+    const float ix = __builtin_amdgcn_rcpf(ray.x), iy = __builtin_amdgcn_rcpf(ray.y), iz = __builtin_amdgcn_rcpf(ray.z);
+    float ax = lo.x * ix, bx = hi.x * ix, ay = lo.y * iy, by = hi.y * iy, az = lo.z * iz, bz = hi.z * iz;
+    if (ray.x == 0) ax = bx = 0.f; // a ray parallel to a slab leaves that axis at [0, 0]
+    if (ray.y == 0) ay = by = 0.f;
+    if (ray.z == 0) az = bz = 0.f;
+    const float mn = hw_min3(hw_max(ax, bx), hw_max(ay, by), hw_max(az, bz));
+    const float mx = hw_max3(hw_min(ax, bx), hw_min(ay, by), hw_min(az, bz));
+    const float largest = hw_max(hw_max3_abs(ax, bx, ay), hw_max3_abs(by, az, bz));
+    const float probe = ((ray.x + ray.y) + ray.z) + finite_probe;
+    const float band = (1e-6f * largest + 1e-30f) + 0.f * probe;
+    const float gap = mn - mx;
+    if (!(fabsf(gap) > band)) return -1;
+    return gap > 0.f ? 1 : 0;
+}
+
+// (Out of line: the rare exact answer must not cost the callers registers.)
+__device__ __attribute__((noinline)) bool box_hit_out_of_line(float lx, float ly, float lz, float hx, float hy, float hz, float rx,
+                                                              float ry, float rz) {
+    return box_hit(mk(lx, ly, lz), mk(hx, hy, hz), mk(rx, ry, rz));
+}
+
+__device__ __forceinline__ bool box_hit_via_verdict(V3 lo, V3 hi, V3 ray, float finite_probe) {
+    const int v = box_verdict(lo, hi, ray, finite_probe);
+    if (v < 0) return box_hit_out_of_line(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, ray.x, ray.y, ray.z); // rare
+    return v != 0;
+}
+
 // Slab test against every box until one is hit (reference
 // src/raytrace.cu:103-145): per axis the entry/exit parameters stay 0 when
 // the ray is parallel to the slab, there is no t > 0 requirement, and the
 // verdict is min(exit) > max(entry).
+// kViaVerdict: decide by box_verdict where that is certain (fewer instructions, more registers).
+template <bool kViaVerdict = false>
 __device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start) {
     bool hit = false;
     for_each_box(sc, c, [&](float4 lo, float4 hi) {
-        if (!hit) hit = box_hit(xyz(lo) - start, xyz(hi) - start, ray);
+        if (!hit) {
+            const V3 l = xyz(lo) - start, h = xyz(hi) - start;
+            if (kViaVerdict) hit = box_hit_via_verdict(l, h, ray, ((l.x + l.y) + (l.z + h.x)) + (h.y + h.z));
+            else hit = box_hit(l, h, ray);
+        }
     });
     return hit;
 }
@@ -373,10 +421,11 @@ __device__ __forceinline__ void add_casts(const Work& w, uint32_t counter, uint3
 
 // True when the ray has to walk the triangle list (reference
 // src/raytrace.cu:103-146: with boxes enabled only after a box hit).
+template <bool kViaVerdict = false>
 __device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, const SceneCache& c, int use_boxes, V3 ray, V3 start) {
     if (sc.n_triangles == 0) return false;
     if (!use_boxes) return true;
-    return any_box_hit(sc, c, ray, start);
+    return any_box_hit<kViaVerdict>(sc, c, ray, start);
 }
 
 // needs_mesh for two rays that leave the same point; box - start is shared.

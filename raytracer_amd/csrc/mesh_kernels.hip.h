@@ -298,10 +298,6 @@ __device__ __forceinline__ void plan_jobs(const uint32_t* __restrict__ count, ui
 // The hardware minimum / maximum: a NaN operand is dropped (minNum / maxNum).
 // Written as instructions because the library functions first re-quiet every
 // operand (v_max x, x), which doubles the cost of a slab test.
-__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // One ray prepared for slab tests: 1/u, origin * (1/u), cut-off distance.
 struct SlabRay {

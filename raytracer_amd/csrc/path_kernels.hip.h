@@ -48,7 +48,8 @@ __device__ __forceinline__ void launch_ray(const DeviceScene& sc, const SceneCac
     bool walk = false;
     if (alive) {
         ts = nearest_sphere(sc, cache, ray, start, sid);
-        walk = needs_mesh(sc, cache, f.bounding_box, ray, start);
+        // (the kernels that call this have registers to spare for the shorter box test)
+        walk = needs_mesh<true>(sc, cache, f.bounding_box, ray, start);
     }
     commit_ray(w, counter, alive, p, start, ray, ts, sid, walk);
 }
