@@ -75,6 +75,29 @@ def test_more_spheres_than_the_lds_cache_holds(tmp_path):
     assert same_bits(img, ref)
 
 
+def test_more_materials_and_objects_than_the_lds_cache_holds(tmp_path):
+    """150 spheres with a material each (the kernels keep 128 materials and 64 spheres in LDS) and
+    eleven meshes (8 object boxes in LDS): the entries beyond are read from global memory."""
+    rng = np.random.default_rng(5)
+    s = random_scene(3, tmp_path)
+    for _ in range(150):
+        s.add_sphere(rng.uniform(-30, 30, 3), float(rng.uniform(0.5, 2)), rng.uniform(0.1, 1.0, 3), int(rng.integers(0, 3)), 1.0, 1.5)
+    v, n, t = make_mesh.bumpy_sphere(6, 9, radius=2.5, bump=0.2)
+    path = tmp_path / "small.obj"
+    make_mesh.write_obj(str(path), v, n, t)
+    for _ in range(11):
+        s.add_object(str(path), rng.uniform(-20, 20, 3), rng.uniform(0.7, 1.3, 3), rng.uniform(0, 360, 3),
+                     rng.uniform(0.1, 1.0, 3), int(rng.integers(0, 3)), 1.0, 1.5)
+    desc, cam = s.describe()
+    assert desc.n_materials > 128 and desc.n_boxes > 8 and desc.n_spheres > 64
+    dev = s.upload()
+    for bbox in (True, False):
+        ref, _ = ob.render_image(desc, cam, ob.options(bounding_box=bbox, seed=5))
+        for culling in (True, False):
+            img, _ = dev.render(cam, rt.make_options(bounding_box=bbox, seed=5, cluster_culling=culling))
+            assert same_bits(img, ref)
+
+
 def test_twelve_lights_with_meshes(tmp_path):
     """Every light's shadow ray may have to wait for the triangle kernel: twelve pending slots per hit."""
     rng = np.random.default_rng(7)
