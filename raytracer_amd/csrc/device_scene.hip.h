@@ -23,7 +23,7 @@ constexpr uint32_t kCastShards = 1024;      // statistics counters per path kern
 constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none)
 constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
 constexpr uint32_t kMaxLights = 64;
-constexpr uint32_t kClusterPairs = 16;      // triangle pairs per culling cluster (32 triangles; swept 4-32 on the cat mesh)
+constexpr uint32_t kClusterPairs = 8;       // triangle pairs per culling cluster of a small mesh (16 triangles; swept 4-32 on the cat mesh)
 constexpr uint32_t kMaxClusters = 64 * 64;  // two levels of at most 64 boxes each; larger meshes get larger clusters
 constexpr size_t kClusterListBudget = size_t(24) << 30; // most bytes the per-cluster ray lists may take (of 288 GB)
 

@@ -421,7 +421,9 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     }
     // Clusters of consecutive pairs and their bounds, padded by 0.05 plus a
     // thousandth of the cluster's diagonal.
-    uint32_t cluster_pairs = kClusterPairs;
+    // 16 triangles per cluster up to 512 clusters, 32 beyond (measured: 3 844 and 3 954 triangles are
+    // faster with 16, 16 128 and 39 600 with 32: the binning work grows with the number of clusters)
+    uint32_t cluster_pairs = n_pairs <= 512 * kClusterPairs ? kClusterPairs : 2 * kClusterPairs;
     if (const char* env = std::getenv("RT_AMD_CLUSTER_PAIRS")) { // tuning / test knob: pairs per cluster
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 1 && v <= 4096) cluster_pairs = (uint32_t)v;
