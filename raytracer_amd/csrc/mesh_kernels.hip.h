@@ -486,20 +486,37 @@ __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__
     plan_jobs(cl_count, n_clusters, first_job, scan);
     const uint32_t n_jobs = first_job[n_clusters];
     const uint32_t n_pairs = (n_tri + 1) / 2;
-    for (uint32_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
-        const uint32_t c = owner_of_job(first_job, n_clusters, job);
-        const uint32_t count = cl_count[c * kCountStride];
-        const uint32_t e = (job - first_job[c]) * kBlock + threadIdx.x;
-        const bool active = e < count;
-        const uint32_t at = cl_list[(size_t)c * list_capacity + (active ? e : count - 1)];
-        const float4 o4 = q_o[2 * (size_t)at];
-        const float4 d4 = q_d[2 * (size_t)at];
-        Nearest best = nearest_init(d4.w);
-        const uint32_t first = c * cluster_pairs;
-        scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
-        if (active && best.index >= 0) {
+    // The ray of the NEXT job is requested before the current one is scanned: a job of a small
+    // cluster is a few hundred instructions, less than the two dependent loads (list entry, ray) take.
+    struct Job {
+        uint32_t cluster;
+        bool active;
+        float4 o4, d4;
+    };
+    auto fetch = [&](uint32_t job) {
+        Job j;
+        j.cluster = owner_of_job(first_job, n_clusters, job);
+        const uint32_t count = cl_count[j.cluster * kCountStride];
+        const uint32_t e = (job - first_job[j.cluster]) * kBlock + threadIdx.x;
+        j.active = e < count;
+        const uint32_t at = cl_list[(size_t)j.cluster * list_capacity + (j.active ? e : count - 1)];
+        j.o4 = q_o[2 * (size_t)at];
+        j.d4 = q_d[2 * (size_t)at];
+        return j;
+    };
+    uint32_t job = blockIdx.x;
+    if (job >= n_jobs) return;
+    Job next = fetch(job);
+    while (job < n_jobs) {
+        const Job cur = next;
+        job += gridDim.x;
+        if (job < n_jobs) next = fetch(job);
+        Nearest best = nearest_init(cur.d4.w);
+        const uint32_t first = cur.cluster * cluster_pairs;
+        scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), cur.o4.x, cur.o4.y, cur.o4.z, cur.d4.x, cur.d4.y, cur.d4.z, best);
+        if (cur.active && best.index >= 0) {
             const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | tri_orig[best.index];
-            atomicMin(&hit[__float_as_uint(o4.w)], key);
+            atomicMin(&hit[__float_as_uint(cur.o4.w)], key);
         }
     }
 }
