@@ -306,7 +306,9 @@ struct SlabRay {
 
 __device__ __forceinline__ SlabRay slab_ray(float4 o4, float4 d4) {
     SlabRay r;
-    r.ix = 1.f / d4.x; r.iy = 1.f / d4.y; r.iz = 1.f / d4.z; // +-inf for an axis-parallel ray
+    // hardware reciprocals (one unit in the last place: nothing next to the padding of the bounds);
+    // +-inf for an axis-parallel ray
+    r.ix = __builtin_amdgcn_rcpf(d4.x); r.iy = __builtin_amdgcn_rcpf(d4.y); r.iz = __builtin_amdgcn_rcpf(d4.z);
     r.ox = o4.x * r.ix; r.oy = o4.y * r.iy; r.oz = o4.z * r.iz;
     r.cutoff = d4.w;
     return r;
