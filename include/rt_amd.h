@@ -84,7 +84,7 @@ typedef struct rt_options {
     int32_t profile;   /* non-zero: time the triangle kernel with events */
     /* 0: every queued ray is tested against every triangle, the reference's
      * scan (src/raytrace.cu:148-175), and every path runs all its bounces.
-     * Non-zero: triangles are grouped into clusters of 32 neighbours and a ray
+     * Non-zero: triangles are grouped into clusters of 16 or 32 neighbours and a ray
      * skips the clusters whose padded bounds it misses; work that can only add
      * exact zeros is dropped (the mesh walk of a shadow ray whose contribution
      * is zero, the remaining bounces of a path whose weight is zero in all

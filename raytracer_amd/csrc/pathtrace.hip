@@ -282,8 +282,12 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
             if ((rc = mark('B')) != RT_OK) return rc;
             const f2* cl_pair = reinterpret_cast<const f2*>(s->d.cl_pair);
             // two ray blocks per workgroup, except for short batches (measured: better from about 2 M paths up)
-            const bool wide = batch_paths >= 1536u * 1024u;
-            const bool wider = batch_paths >= 6u * 1024u * 1024u;
+            bool wide = batch_paths >= 1536u * 1024u;
+            bool wider = batch_paths >= 6u * 1024u * 1024u;
+            static const int forced = [] { const char* e = std::getenv("RT_AMD_BIN_RAYS"); return e ? std::atoi(e) : 0; }(); // tuning knob
+            if (forced == 1) wide = wider = false;
+            if (forced == 2) { wide = true; wider = false; }
+            if (forced == 4) wide = wider = true;
             auto bin64 = wider ? k_bin64<4> : wide ? k_bin64<2> : k_bin64<1>;
             if (s->d.n_groups == 0) {
                 hipLaunchKernelGGL(bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc,
