@@ -284,28 +284,31 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
             // two ray blocks per workgroup, except for short batches (measured: better from about 2 M paths up)
             bool wide = batch_paths >= 1536u * 1024u;
             bool wider = batch_paths >= 6u * 1024u * 1024u;
+            // twice the workgroups that fit at once: the second half starts as the first finishes, which
+            // evens out the jobs of a short stage (measured: 1-2 % of the frame)
+            const uint32_t bin_grid = 2 * kMeshGrid, cl_grid = 2 * kMeshGrid;
             static const int forced = [] { const char* e = std::getenv("RT_AMD_BIN_RAYS"); return e ? std::atoi(e) : 0; }(); // tuning knob
             if (forced == 1) wide = wider = false;
             if (forced == 2) { wide = true; wider = false; }
             if (forced == 4) wide = wider = true;
             auto bin64 = wider ? k_bin64<4> : wide ? k_bin64<2> : k_bin64<1>;
             if (s->d.n_groups == 0) {
-                hipLaunchKernelGGL(bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc,
+                hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, cl_pair, nc,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
                                    tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list, s->w.list_capacity);
             } else {
                 const uint32_t ng = s->d.n_groups;
                 uint32_t* grp_count = s->w.grp_count + slot * ng * kCountStride;
-                hipLaunchKernelGGL(bin64, dim3(kMeshGrid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
+                hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
                                    tile * blocks_per_tile, blocks_per_tile, grp_count, s->w.grp_list, s->w.list_capacity);
                 auto bin_groups = wider ? k_bin_groups<4> : wide ? k_bin_groups<2> : k_bin_groups<1>;
-                hipLaunchKernelGGL(bin_groups, dim3(kMeshGrid), dim3(kBlock), 0, stream, cl_pair, nc, ng, s->d.group_clusters,
+                hipLaunchKernelGGL(bin_groups, dim3(bin_grid), dim3(kBlock), 0, stream, cl_pair, nc, ng, s->d.group_clusters,
                                    (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)grp_count,
                                    (const uint32_t*)s->w.grp_list, cl_count, s->w.cl_list, s->w.list_capacity);
             }
             if ((rc = mark('M')) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_mesh_clusters, dim3(kMeshGrid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
+            hipLaunchKernelGGL(k_mesh_clusters, dim3(cl_grid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
                                s->d.cluster_pairs, (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)cl_count,
                                (const uint32_t*)s->w.cl_list, s->w.list_capacity, s->w.hit);
             if ((rc = mark('E')) != RT_OK) return rc;
