@@ -36,8 +36,9 @@ def main():
     out = {}
     shares = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
     for n in shares:
-        for overlapped in ("four handles", "three handles", "two handles", True, False):
-            extra = [scene.upload() for _ in range({"four handles": 3, "three handles": 2, "two handles": 1}.get(overlapped, 0))]
+        for overlapped in ("eight handles", "six handles", "four handles", "three handles", "two handles", True, False):
+            extra = [scene.upload() for _ in range({"eight handles": 7, "six handles": 5, "four handles": 3, "three handles": 2,
+                                                    "two handles": 1}.get(overlapped, 0))]
             r = FrameRenderer(dev, cam, opt, exchange_in_group_of_one=True, extra_devs=extra)
             r.s_begin, r.s_end = sample_range(0, n, cam.num_rays)  # rank 0's share of an n-rank run; all rows
             step = r.render_async if overlapped else r.render
