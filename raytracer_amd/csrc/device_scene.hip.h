@@ -60,11 +60,23 @@ struct DeviceScene {
 };
 
 // Per-batch path state and queues.
+// One float4 of a record of kStride float4 per path.  The ray of a path (origin, direction) is one
+// 32-byte record, as in the queue: the bounces after the first gather their paths through the list
+// of live ones, and a gathered ray then costs one memory sector instead of two.  (Measured: pairing
+// albedo and colour as well, or all four in 64 bytes, slows the first two bounces -- which read
+// consecutive paths -- and k_accumulate by more than it saves later.)
+template <int kStride>
+struct PathField {
+    float4* base;
+    __device__ __forceinline__ float4& operator[](size_t p) const { return base[kStride * p]; }
+};
+constexpr int kRayStride = 2, kRadStride = 1;
+
 struct Work {
-    float4* ray_o;   // origin.xyz, nearest-sphere distance
-    float4* ray_d;   // direction.xyz, nearest-sphere index as int bits
-    float4* thr;     // albedo.xyz, next random dimension as uint bits
-    float4* rad;     // colour L.xyz, F_* flags as uint bits
+    PathField<kRayStride> ray_o;   // origin.xyz, nearest-sphere distance
+    PathField<kRayStride> ray_d;   // direction.xyz, nearest-sphere index as int bits
+    PathField<kRadStride> thr;     // albedo.xyz, next random dimension as uint bits
+    PathField<kRadStride> rad;     // colour L.xyz, F_* flags as uint bits
     float4* pend;    // n_lights per path: contribution.xyz, light distance or PEND_*
     unsigned long long* hit; // paths + paths*n_lights slots: (t bits << 32) | triangle
     // the ray queue: 32-byte records (origin.xyz, hit slot as uint bits | direction.xyz, cut-off

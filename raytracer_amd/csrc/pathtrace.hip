@@ -206,8 +206,8 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t cl_words = slots_cl * nc * kCountStride, grp_words = slots_cl * ng * kCountStride;
     const size_t live_capacity = ((n_waves + kShards - 1) / kShards) * 64; // a wavefront keeps at most its 64 paths
     int rc;
-    if ((rc = work_alloc(s, &s->w.ray_o, n_paths)) || (rc = work_alloc(s, &s->w.ray_d, n_paths)) ||
-        (rc = work_alloc(s, &s->w.thr, n_paths)) || (rc = work_alloc(s, &s->w.rad, n_paths)) ||
+    float4* state = nullptr; // (ray_o, ray_d) records | thr | rad
+    if ((rc = work_alloc(s, &state, (size_t)n_paths * 4)) ||
         (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
         (rc = work_alloc(s, &s->w.q_o, 2 * queue_entries)) ||
         (rc = work_alloc(s, &s->w.q_count, 2 * q_words + cl_words + grp_words)) || // one block: cleared with one fill
@@ -218,6 +218,11 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
         free_work(s);
         return rc;
     }
+    static_assert(kRayStride == 2 && kRadStride == 1, "layout of the path state below");
+    s->w.ray_o.base = state;
+    s->w.ray_d.base = state + 1;
+    s->w.thr.base = state + 2 * (size_t)n_paths;
+    s->w.rad.base = state + 3 * (size_t)n_paths;
     s->w.q_d = s->w.q_o + 1;
     s->w.live_count = s->w.q_count + q_words;
     s->w.cl_count = s->w.live_count + q_words;
