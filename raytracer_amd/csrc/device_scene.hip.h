@@ -60,25 +60,27 @@ struct DeviceScene {
 };
 
 // Per-batch path state and queues.
-// One float4 of a record of kStride float4 per path.  The ray of a path (origin, direction) is one
-// 32-byte record, as in the queue: the bounces after the first gather their paths through the list
-// of live ones, and a gathered ray then costs one memory sector instead of two.  (Measured: pairing
-// albedo and colour as well, or all four in 64 bytes, slows the first two bounces -- which read
-// consecutive paths -- and k_accumulate by more than it saves later.)
+// One float4 of a record of kStride float4.
 template <int kStride>
 struct PathField {
     float4* base;
-    __device__ __forceinline__ float4& operator[](size_t p) const { return base[kStride * p]; }
+    __device__ __forceinline__ float4& operator[](size_t i) const { return base[kStride * i]; }
 };
-constexpr int kRayStride = 2, kRadStride = 1;
 
 struct Work {
-    PathField<kRayStride> ray_o;   // origin.xyz, nearest-sphere distance
-    PathField<kRayStride> ray_d;   // direction.xyz, nearest-sphere index as int bits
-    PathField<kRadStride> thr;     // albedo.xyz, next random dimension as uint bits
-    PathField<kRadStride> rad;     // colour L.xyz, F_* flags as uint bits
+    // Per LIVE path, at its position in the list of live paths (two buffers of live_total entries:
+    // bounce d reads buffer d & 1 at index (d & 1) * live_total + position and fills the other one;
+    // the camera rays are at the path's own index in buffer 0).  What a bounce reads of its paths'
+    // rays is therefore contiguous however many paths have ended.
+    PathField<2> ray_o;   // origin.xyz, nearest-sphere distance
+    PathField<2> ray_d;   // direction.xyz, nearest-sphere index as int bits   (one 32-byte record with ray_o)
+    // Per path, at the path's index:
+    PathField<2> thr;     // albedo.xyz, next random dimension as uint bits
+    PathField<2> rad;     // colour L.xyz, F_* flags as uint bits              (one 32-byte record with thr)
     float4* pend;    // n_lights per path: contribution.xyz, light distance or PEND_*
-    unsigned long long* hit; // paths + paths*n_lights slots: (t bits << 32) | triangle
+    // (t bits << 32) | triangle per ray: 2 * live_total slots for the bounce rays (indexed like ray_o),
+    // then paths * n_lights slots for the shadow rays (path * n_lights + light)
+    unsigned long long* hit;
     // the ray queue: 32-byte records (origin.xyz, hit slot as uint bits | direction.xyz, cut-off
     // distance), so that a gather through a cluster list touches one line per ray;
     // entry i is q_o[2 i] and q_d[2 i], with q_d = q_o + 1
@@ -98,6 +100,7 @@ struct Work {
     uint32_t* live;
     uint32_t* live_count;    // kShards counters per bounce
     uint32_t live_capacity;  // path indices reserved per shard
+    uint32_t live_total;     // = kShards * live_capacity: entries of one buffer
 };
 
 struct V3 {
@@ -388,14 +391,19 @@ __device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, boo
     return at;
 }
 
-// The end of a bounce for a wavefront, ALL of whose lanes must call it: queues a shadow ray
-// (want_a) and the bounce ray (want_b) for triangle stage `counter`, and appends `entry` to the
-// list of live paths that bounce `counter` reads (want_live).  Both reservations are issued
-// together by lane 0, so the wavefront waits for one round trip to the counters instead of three.
-__device__ __forceinline__ void enqueue_pair_and_live(const Work& w, uint32_t counter, bool want_a, V3 start_a, V3 ray_a, uint32_t slot_a,
-                                                      float cutoff_a, bool want_b, V3 start_b, V3 ray_b, uint32_t slot_b, float cutoff_b,
-                                                      bool want_live, uint32_t entry) {
-    const unsigned long long mask_a = __ballot(want_a), mask_b = __ballot(want_b), mask_l = __ballot(want_live);
+// Index of the first shadow-ray slot in Work::hit.
+__device__ __forceinline__ size_t shadow_base(const Work& w) { return 2 * (size_t)w.live_total; }
+
+// The end of a bounce for a wavefront, ALL of whose lanes must call it.  A path that goes on
+// (alive) gets a position in the list of live paths that bounce `counter` reads: its list entry,
+// its bounce ray (start, ray_b, nearest sphere ts_b / sid_b) and an empty hit slot are written
+// there, and the ray is queued for triangle stage `counter` if it has to walk the mesh (walk_b).
+// A shadow ray (want_a) is queued with it.  The two reservations are issued together by lane 0,
+// so the wavefront waits for one round trip to the counters instead of three.
+__device__ __forceinline__ void finish_bounce(const Work& w, uint32_t counter, bool want_a, V3 start, V3 ray_a, uint32_t slot_a,
+                                              float cutoff_a, bool alive, bool walk_b, V3 ray_b, float ts_b, int sid_b, uint32_t entry) {
+    const bool want_b = alive && walk_b;
+    const unsigned long long mask_a = __ballot(want_a), mask_b = __ballot(want_b), mask_l = __ballot(alive);
     const uint32_t n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b), n_l = (uint32_t)__popcll(mask_l);
     const uint32_t lane = __lane_id();
     const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
@@ -409,16 +417,21 @@ __device__ __forceinline__ void enqueue_pair_and_live(const Work& w, uint32_t co
     const unsigned long long below = (1ULL << lane) - 1ULL;
     if (want_a) {
         const size_t at = shard * w.shard_capacity + base_q + (uint32_t)__popcll(mask_a & below);
-        w.q_o[2 * at] = make_float4(start_a.x, start_a.y, start_a.z, __uint_as_float(slot_a));
+        w.q_o[2 * at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot_a));
         w.q_d[2 * at] = make_float4(ray_a.x, ray_a.y, ray_a.z, cutoff_a);
     }
-    if (want_b) {
-        const size_t at = shard * w.shard_capacity + base_q + n_a + (uint32_t)__popcll(mask_b & below);
-        w.q_o[2 * at] = make_float4(start_b.x, start_b.y, start_b.z, __uint_as_float(slot_b));
-        w.q_d[2 * at] = make_float4(ray_b.x, ray_b.y, ray_b.z, cutoff_b);
+    if (alive) {
+        const uint32_t index = (counter & 1u) * w.live_total + shard * w.live_capacity + base_l + (uint32_t)__popcll(mask_l & below);
+        w.live[index] = entry;
+        w.ray_o[index] = make_float4(start.x, start.y, start.z, ts_b);
+        w.ray_d[index] = make_float4(ray_b.x, ray_b.y, ray_b.z, __int_as_float(sid_b));
+        w.hit[index] = kNoHit;
+        if (walk_b) {
+            const size_t at = shard * w.shard_capacity + base_q + n_a + (uint32_t)__popcll(mask_b & below);
+            w.q_o[2 * at] = make_float4(start.x, start.y, start.z, __uint_as_float(index));
+            w.q_d[2 * at] = make_float4(ray_b.x, ray_b.y, ray_b.z, ts_b);
+        }
     }
-    if (want_live)
-        w.live[((size_t)(counter & 1u) * kShards + shard) * w.live_capacity + base_l + (uint32_t)__popcll(mask_l & below)] = entry;
 }
 
 // Statistics: adds n (the wavefront's number of rays tested against the

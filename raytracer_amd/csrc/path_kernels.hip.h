@@ -182,7 +182,7 @@ __device__ __forceinline__ V3 settle_pending(const DeviceScene& sc, const Work& 
         if (pe.w == PEND_NONE) continue;
         bool visible = true;
         if (pe.w != PEND_ALWAYS) {
-            const unsigned long long key = fetched ? first_key : w.hit[(size_t)n_paths + (size_t)p * sc.n_lights + l];
+            const unsigned long long key = fetched ? first_key : w.hit[shadow_base(w) + (size_t)p * sc.n_lights + l];
             visible = !(__uint_as_float((uint32_t)(key >> 32)) < pe.w);
         }
         if (visible) L = L + mk(pe.x, pe.y, pe.z);
@@ -234,14 +234,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     // left alive, so that the lanes of a wavefront are all busy however many paths have ended.
     // A list entry is the path index, with kLivePending set when light terms of the previous
     // hit await their shadow rays.
+    // The path's ray and hit slot sit at its position in the list (`index`); the camera rays of the
+    // first bounce at the path's own index.
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t index = p;
     bool pending = false;
     if (depth > 0) {
         const ShardMap map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
         if (blockIdx.x >= map.n_ray_blocks) return; // the whole workgroup
         bool active;
-        const uint32_t at = ray_position(map, blockIdx.x, w.live_capacity, active);
-        const uint32_t entry = active ? w.live[(size_t)(depth & 1) * kShards * w.live_capacity + at] : 0xffffffffu;
+        index = (uint32_t)(depth & 1) * w.live_total + ray_position(map, blockIdx.x, w.live_capacity, active);
+        const uint32_t entry = active ? w.live[index] : 0xffffffffu;
         p = active ? (entry & ~kLivePending) : 0xffffffffu;
         pending = active && (entry & kLivePending) != 0;
     }
@@ -256,14 +259,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     uint32_t flags = 0;
     if (p < f.n_paths) {
         // the whole state of the path in one round trip to memory
-        const float4 rad = w.rad[p];
-        const float4 ro4 = w.ray_o[p], rd4 = w.ray_d[p], th = w.thr[p];
-        const unsigned long long key = w.hit[p];
+        const float4 rad = w.rad[p], th = w.thr[p];
+        const float4 ro4 = w.ray_o[index], rd4 = w.ray_d[index];
+        const unsigned long long key = w.hit[index];
         float4 first_pend = make_float4(0.f, 0.f, 0.f, PEND_NONE);
         unsigned long long first_key = kNoHit;
         if (pending) {
             first_pend = w.pend[(size_t)p * sc.n_lights];
-            first_key = w.hit[(size_t)f.n_paths + (size_t)p * sc.n_lights];
+            first_key = w.hit[shadow_base(w) + (size_t)p * sc.n_lights];
         }
         flags = __float_as_uint(rad.w);
         if (flags & F_ALIVE) {
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                     for (uint32_t e = 0; e < l; e++) w.pend[(size_t)p * sc.n_lights + e].w = PEND_NONE;
                 deferred = true;
                 w.pend[slot] = make_float4(c.x, c.y, c.z, dist);
-                w.hit[(size_t)f.n_paths + slot] = kNoHit;
+                w.hit[shadow_base(w) + slot] = kNoHit;
             } else if (deferred) {
                 w.pend[slot] = make_float4(c.x, c.y, c.z, PEND_ALWAYS);
             } else {
@@ -431,12 +434,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
             }
         }
         if (l + 1 < sc.n_lights) {
-            enqueue(w, counter, lit && shadow_walk, start, sray, (uint32_t)(f.n_paths + slot), dist);
+            enqueue(w, counter, lit && shadow_walk, start, sray, (uint32_t)(shadow_base(w) + slot), dist);
         } else {
             last_want = lit && shadow_walk;
             last_sray = sray;
             last_dist = dist;
-            last_slot = (uint32_t)(f.n_paths + slot);
+            last_slot = (uint32_t)(shadow_base(w) + slot);
         }
     }
     if (f.count_casts)
@@ -450,13 +453,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
         ts = nearest_sphere(sc, cache, ray, start, sid);
         walk = needs_mesh(sc, cache, f.bounding_box, ray, start);
     }
-    if (alive) { // state of the bounce ray (as commit_ray)
-        w.ray_o[p] = make_float4(start.x, start.y, start.z, ts);
-        w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
-        w.hit[p] = kNoHit;
-    }
-    enqueue_pair_and_live(w, counter, last_want, start, last_sray, last_slot, last_dist, alive && walk, start, ray, p, ts,
-                          alive, p | (deferred ? kLivePending : 0u));
+    finish_bounce(w, counter, last_want, start, last_sray, last_slot, last_dist, alive, walk, ray, ts, sid,
+                  p | (deferred ? kLivePending : 0u));
 }
 
 // Per pixel: add the batch's sample colours to the running sum in sample

@@ -175,7 +175,6 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     if (s->work_paths >= n_paths && s->n_counters >= n_counters) return RT_OK;
     free_work(s);
     const size_t nl = s->d.n_lights ? s->d.n_lights : 1;
-    const size_t slots = (size_t)n_paths * (1 + nl);
     // a shard receives the rays of every kShards-th wavefront of a path kernel
     // (k_shade walks its list of live paths shard by shard, every shard ending in a partial workgroup:
     // up to kShards workgroups more than the paths need)
@@ -206,9 +205,12 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t cl_words = slots_cl * nc * kCountStride, grp_words = slots_cl * ng * kCountStride;
     const size_t live_capacity = ((n_waves + kShards - 1) / kShards) * 64; // a wavefront keeps at most its 64 paths
     int rc;
-    float4* state = nullptr; // (ray_o, ray_d) records | thr | rad
-    if ((rc = work_alloc(s, &state, (size_t)n_paths * 4)) ||
-        (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, slots)) ||
+    const size_t live_total = kShards * live_capacity; // >= n_paths: buffer 0 also holds the camera rays at the paths' own indices
+    if (2 * live_total + (size_t)n_paths * nl > 0xffffffffu) { rt_set_error("batch too large for 32-bit hit slots"); return RT_ERR_INVALID; }
+    float4* rays = nullptr;   // (ray_o, ray_d) records, two buffers of live_total
+    float4* state = nullptr;  // (thr, rad) records per path
+    if ((rc = work_alloc(s, &rays, 4 * live_total)) || (rc = work_alloc(s, &state, (size_t)n_paths * 2)) ||
+        (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, 2 * live_total + (size_t)n_paths * nl)) ||
         (rc = work_alloc(s, &s->w.q_o, 2 * queue_entries)) ||
         (rc = work_alloc(s, &s->w.q_count, 2 * q_words + cl_words + grp_words)) || // one block: cleared with one fill
         (rc = work_alloc(s, &s->w.live, 2 * kShards * live_capacity)) ||
@@ -218,11 +220,11 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
         free_work(s);
         return rc;
     }
-    static_assert(kRayStride == 2 && kRadStride == 1, "layout of the path state below");
-    s->w.ray_o.base = state;
-    s->w.ray_d.base = state + 1;
-    s->w.thr.base = state + 2 * (size_t)n_paths;
-    s->w.rad.base = state + 3 * (size_t)n_paths;
+    s->w.ray_o.base = rays;
+    s->w.ray_d.base = rays + 1;
+    s->w.thr.base = state;
+    s->w.rad.base = state + 1;
+    s->w.live_total = (uint32_t)live_total;
     s->w.q_d = s->w.q_o + 1;
     s->w.live_count = s->w.q_count + q_words;
     s->w.cl_count = s->w.live_count + q_words;
