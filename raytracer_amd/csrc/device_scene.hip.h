@@ -75,8 +75,10 @@ struct Work {
     PathField<2> ray_o;   // origin.xyz, nearest-sphere distance
     PathField<2> ray_d;   // direction.xyz, nearest-sphere index as int bits   (one 32-byte record with ray_o)
     // Per path, at the path's index:
-    PathField<2> thr;     // albedo.xyz, next random dimension as uint bits
-    PathField<2> rad;     // colour L.xyz, F_* flags as uint bits              (one 32-byte record with thr)
+    // (two arrays: as one 32-byte record they slow the first bounces and k_accumulate, which read
+    // consecutive paths, by more than the later bounces gain)
+    float4* thr;     // albedo.xyz, next random dimension as uint bits
+    float4* rad;     // colour L.xyz, F_* flags as uint bits
     float4* pend;    // n_lights per path: contribution.xyz, light distance or PEND_*
     // (t bits << 32) | triangle per ray: 2 * live_total slots for the bounce rays (indexed like ray_o),
     // then paths * n_lights slots for the shadow rays (path * n_lights + light)
