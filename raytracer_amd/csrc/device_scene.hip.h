@@ -74,10 +74,8 @@ struct Work {
     // rays is therefore contiguous however many paths have ended.
     PathField<2> ray_o;   // origin.xyz, nearest-sphere distance
     PathField<2> ray_d;   // direction.xyz, nearest-sphere index as int bits   (one 32-byte record with ray_o)
+    float4* thr;          // albedo.xyz, next random dimension as uint bits
     // Per path, at the path's index:
-    // (two arrays: as one 32-byte record they slow the first bounces and k_accumulate, which read
-    // consecutive paths, by more than the later bounces gain)
-    float4* thr;     // albedo.xyz, next random dimension as uint bits
     float4* rad;     // colour L.xyz, F_* flags as uint bits
     float4* pend;    // n_lights per path: contribution.xyz, light distance or PEND_*
     // (t bits << 32) | triangle per ray: 2 * live_total slots for the bounce rays (indexed like ray_o),
@@ -403,7 +401,8 @@ __device__ __forceinline__ size_t shadow_base(const Work& w) { return 2 * (size_
 // A shadow ray (want_a) is queued with it.  The two reservations are issued together by lane 0,
 // so the wavefront waits for one round trip to the counters instead of three.
 __device__ __forceinline__ void finish_bounce(const Work& w, uint32_t counter, bool want_a, V3 start, V3 ray_a, uint32_t slot_a,
-                                              float cutoff_a, bool alive, bool walk_b, V3 ray_b, float ts_b, int sid_b, uint32_t entry) {
+                                              float cutoff_a, bool alive, bool walk_b, V3 ray_b, float ts_b, int sid_b, float4 thr,
+                                              uint32_t entry) {
     const bool want_b = alive && walk_b;
     const unsigned long long mask_a = __ballot(want_a), mask_b = __ballot(want_b), mask_l = __ballot(alive);
     const uint32_t n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b), n_l = (uint32_t)__popcll(mask_l);
@@ -427,6 +426,7 @@ __device__ __forceinline__ void finish_bounce(const Work& w, uint32_t counter, b
         w.live[index] = entry;
         w.ray_o[index] = make_float4(start.x, start.y, start.z, ts_b);
         w.ray_d[index] = make_float4(ray_b.x, ray_b.y, ray_b.z, __int_as_float(sid_b));
+        w.thr[index] = thr;
         w.hit[index] = kNoHit;
         if (walk_b) {
             const size_t at = shard * w.shard_capacity + base_q + n_a + (uint32_t)__popcll(mask_b & below);

@@ -257,10 +257,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     V3 P = mk(0, 0, 0), N = mk(0, 0, 1), L = mk(0, 0, 0);
     V3 weight = mk(0, 0, 0), colour = mk(0, 0, 0); // path weight before this hit, surface colour
     uint32_t flags = 0;
+    uint32_t next_dim = 0;     // next random dimension of the path after this bounce
+    bool tinted = false;       // the weight after this bounce is weight * colour (diffuse hit with indirect light)
     if (p < f.n_paths) {
         // the whole state of the path in one round trip to memory
-        const float4 rad = w.rad[p], th = w.thr[p];
-        const float4 ro4 = w.ray_o[index], rd4 = w.ray_d[index];
+        const float4 rad = w.rad[p];
+        const float4 ro4 = w.ray_o[index], rd4 = w.ray_d[index], th = w.thr[index];
         const unsigned long long key = w.hit[index];
         float4 first_pend = make_float4(0.f, 0.f, 0.f, PEND_NONE);
         unsigned long long first_key = kNoHit;
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                         alive = false;
                     } else {
                         next_weight = weight * colour;
+                        tinted = true;
                         const float r1 = rt_rng_uniform(rng, dim);
                         const float r2 = rt_rng_uniform(rng, dim + 1);
                         dim += 2;
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                 // green one) stays zero, and every later term of the path is weight * direct light
                 // with a finite direct light: the path has nothing more to add.
                 if (f.prune_zero_terms && next_weight.x == 0.f && next_weight.y == 0.f && next_weight.z == 0.f) alive = false;
-                w.thr[p] = make_float4(next_weight.x, next_weight.y, next_weight.z, __uint_as_float(dim));
+                next_dim = dim;
             }
         }
     }
@@ -453,8 +456,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
         ts = nearest_sphere(sc, cache, ray, start, sid);
         walk = needs_mesh(sc, cache, f.bounding_box, ray, start);
     }
+    // (the product again rather than three registers kept across the lights: same operands, same bits)
+    const V3 next_weight = tinted ? weight * colour : weight;
     finish_bounce(w, counter, last_want, start, last_sray, last_slot, last_dist, alive, walk, ray, ts, sid,
-                  p | (deferred ? kLivePending : 0u));
+                  make_float4(next_weight.x, next_weight.y, next_weight.z, __uint_as_float(next_dim)), p | (deferred ? kLivePending : 0u));
 }
 
 // Per pixel: add the batch's sample colours to the running sum in sample

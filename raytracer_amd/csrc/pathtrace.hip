@@ -208,8 +208,8 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t live_total = kShards * live_capacity; // >= n_paths: buffer 0 also holds the camera rays at the paths' own indices
     if (2 * live_total + (size_t)n_paths * nl > 0xffffffffu) { rt_set_error("batch too large for 32-bit hit slots"); return RT_ERR_INVALID; }
     float4* rays = nullptr;   // (ray_o, ray_d) records, two buffers of live_total
-    float4* state = nullptr;  // thr | rad, per path
-    if ((rc = work_alloc(s, &rays, 4 * live_total)) || (rc = work_alloc(s, &state, (size_t)n_paths * 2)) ||
+    if ((rc = work_alloc(s, &rays, 4 * live_total)) || (rc = work_alloc(s, &s->w.thr, 2 * live_total)) ||
+        (rc = work_alloc(s, &s->w.rad, n_paths)) ||
         (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, 2 * live_total + (size_t)n_paths * nl)) ||
         (rc = work_alloc(s, &s->w.q_o, 2 * queue_entries)) ||
         (rc = work_alloc(s, &s->w.q_count, 2 * q_words + cl_words + grp_words)) || // one block: cleared with one fill
@@ -222,8 +222,6 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     }
     s->w.ray_o.base = rays;
     s->w.ray_d.base = rays + 1;
-    s->w.thr = state;
-    s->w.rad = state + n_paths;
     s->w.live_total = (uint32_t)live_total;
     s->w.q_d = s->w.q_o + 1;
     s->w.live_count = s->w.q_count + q_words;
