@@ -7,6 +7,7 @@ collective's launch path and the stream overlap are exercised; the transfer
 itself is missing) and reports ms per frame.  ms(1) / ms(N) is an upper bound
 of the strong-scaling factor bench.py --gpus N can reach.
 """
+import gc
 import json
 import os
 import sys
@@ -36,9 +37,10 @@ def main():
     out = {}
     shares = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
     for n in shares:
-        for overlapped in ("eight handles", "six handles", "four handles", "three handles", "two handles", True, False):
-            extra = [scene.upload() for _ in range({"eight handles": 7, "six handles": 5, "four handles": 3, "three handles": 2,
-                                                    "two handles": 1}.get(overlapped, 0))]
+        for overlapped in ("four handles", "three handles", "two handles", True, False):
+            r = extra = None  # frees the previous arrangement's handles (each holds gigabytes of ray lists) before new ones are made
+            gc.collect()
+            extra = [scene.upload() for _ in range({"four handles": 3, "three handles": 2, "two handles": 1}.get(overlapped, 0))]
             r = FrameRenderer(dev, cam, opt, exchange_in_group_of_one=True, extra_devs=extra)
             r.s_begin, r.s_end = sample_range(0, n, cam.num_rays)  # rank 0's share of an n-rank run; all rows
             step = r.render_async if overlapped else r.render
