@@ -289,9 +289,12 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
             // two ray blocks per workgroup, except for short batches (measured: better from about 2 M paths up)
             bool wide = batch_paths >= 1536u * 1024u;
             bool wider = batch_paths >= 6u * 1024u * 1024u;
-            // twice the workgroups that fit at once: the second half starts as the first finishes, which
-            // evens out the jobs of a short stage (measured: 1-2 % of the frame)
-            const uint32_t bin_grid = 2 * kMeshGrid, cl_grid = 2 * kMeshGrid;
+            // Half the resident workgroups for batches below 6 M paths: every workgroup of these grids pays a
+            // set-up (shard map, job table) whether it finds work or not, and with several frames in flight
+            // the short stages of small batches are mostly set-up.  (Measured with three frames in flight:
+            // 2 048 workgroups are best at 8.4 M paths, 1 024 at 4.2 M and below -- 9 % at 1 M; a frame
+            // rendered alone loses 2 % against 4 096.)
+            const uint32_t bin_grid = batch_paths >= 6u * 1024u * 1024u ? kMeshGrid : kMeshGrid / 2, cl_grid = bin_grid;
             static const int forced = [] { const char* e = std::getenv("RT_AMD_BIN_RAYS"); return e ? std::atoi(e) : 0; }(); // tuning knob
             if (forced == 1) wide = wider = false;
             if (forced == 2) { wide = true; wider = false; }
