@@ -88,7 +88,16 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
     __shared__ SceneCache cache;
     __shared__ uint32_t key_kp[kPaths][kBlock], key_ks[kPaths][kBlock];
     __shared__ uint32_t accepted[kPaths][kBlock]; // first dimension of the accepted draw
+    __shared__ float4 eye_oc[kSphereCache];       // per cached sphere: OC = eye - centre, |OC| * |OC|
     stage_scene(sc, cache);
+    // every camera ray starts at the eye: the start-dependent half of the sphere test is the same
+    // for all paths and is computed once per workgroup (same operations, same bits)
+    if (threadIdx.x < min(sc.n_spheres, kSphereCache)) {
+        const V3 oc = mk(f.pos[0], f.pos[1], f.pos[2]) - xyz(cache.sphere[threadIdx.x]);
+        const float ocn = norm(oc);
+        eye_oc[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, ocn * ocn);
+    }
+    __syncthreads();
     const uint32_t base = blockIdx.x * (kBlock * kPaths) + threadIdx.x;
     // only this lane reads what it writes to the three arrays: no barrier needed
     uint32_t owned = 0;
@@ -164,7 +173,25 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
             w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
         }
-        launch_ray(sc, cache, w, f, 0, alive, p, start, ray);
+        int sid = -1;
+        float ts = INFINITY;
+        bool walk = false;
+        if (alive) {
+            // nearest_sphere with the precomputed halves
+            const uint32_t cached = min(sc.n_spheres, kSphereCache);
+            for (uint32_t i = 0; i < cached; i++) {
+                const float4 e = eye_oc[i];
+                sphere_step(dot(ray, xyz(e)), e.w, cache.sphere[i].w, i, ts, sid);
+            }
+            for (uint32_t i = cached; i < sc.n_spheres; i++) {
+                const float4 sph = sc.sphere[i];
+                const V3 oc = start - xyz(sph);
+                const float ocn = norm(oc);
+                sphere_step(dot(ray, oc), ocn * ocn, sph.w, i, ts, sid);
+            }
+            walk = needs_mesh<true>(sc, cache, f.bounding_box, ray, start);
+        }
+        commit_ray(w, 0, alive, p, start, ray, ts, sid, walk);
         n_casts += (uint32_t)__popcll(__ballot(alive));
     }
     if (f.count_casts) add_casts(w, 0, n_casts);
