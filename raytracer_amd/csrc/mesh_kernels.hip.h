@@ -251,13 +251,16 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
 
 // Index of the last entry of first[0..n) that is <= job (entries are
 // non-decreasing; empty ranges share their successor's value).
+// A 64-ary search by the whole wavefront (all lanes must call it with the same job): two LDS reads
+// instead of the twelve dependent ones of a binary search over 4 096 entries.
 __device__ __forceinline__ uint32_t owner_of_job(const uint32_t* first, uint32_t n, uint32_t job) {
-    uint32_t lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) / 2;
-        if (first[mid] <= job) lo = mid; else hi = mid - 1;
-    }
-    return lo;
+    const uint32_t lane = __lane_id();
+    const uint32_t coarse = lane * 64u;
+    const uint32_t v = coarse < n ? first[coarse] : 0xffffffffu;
+    const uint32_t block = (uint32_t)__popcll(__ballot(v <= job)) - 1u; // first[0] = 0 <= job
+    const uint32_t fine = block * 64u + lane;
+    const uint32_t u = fine < n ? first[fine] : 0xffffffffu;
+    return block * 64u + (uint32_t)__popcll(__ballot(u <= job)) - 1u;
 }
 
 // first_job[i] = number of jobs (of job_entries list entries) of the lists before list i,
@@ -488,31 +491,49 @@ __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__
     plan_jobs(cl_count, n_clusters, first_job, scan);
     const uint32_t n_jobs = first_job[n_clusters];
     const uint32_t n_pairs = (n_tri + 1) / 2;
-    // The ray of the NEXT job is requested before the current one is scanned: a job of a small
-    // cluster is a few hundred instructions, less than the two dependent loads (list entry, ray) take.
-    struct Job {
+    // A job is a few hundred instructions, less than the three dependent accesses (job table, list
+    // entry, ray) take, and a wavefront waits in order.  So the loop is a pipeline: in one trip it
+    // requests the list entries of the job after next, requests the rays of the next job (whose list
+    // entries were requested a trip ago) and scans the current job (whose rays were requested a trip ago).
+    struct Where { // stage A: the job's list entries, requested
+        uint32_t cluster, entry, count, at;
+    };
+    struct Job {   // stage B: the job's rays, requested
         uint32_t cluster;
         bool active;
         float4 o4, d4;
     };
-    auto fetch = [&](uint32_t job) {
+    auto locate = [&](uint32_t job) {
+        Where a;
+        a.cluster = owner_of_job(first_job, n_clusters, job);
+        a.entry = (job - first_job[a.cluster]) * kBlock + threadIdx.x;
+        a.count = cl_count[a.cluster * kCountStride];
+        // within the list's capacity (a multiple of kBlock) even past its end; such lanes are masked below
+        a.at = cl_list[(size_t)a.cluster * list_capacity + a.entry];
+        return a;
+    };
+    auto request = [&](const Where& a) {
         Job j;
-        j.cluster = owner_of_job(first_job, n_clusters, job);
-        const uint32_t count = cl_count[j.cluster * kCountStride];
-        const uint32_t e = (job - first_job[j.cluster]) * kBlock + threadIdx.x;
-        j.active = e < count;
-        const uint32_t at = cl_list[(size_t)j.cluster * list_capacity + (j.active ? e : count - 1)];
+        j.cluster = a.cluster;
+        j.active = a.entry < a.count;
+        const uint32_t at = j.active ? a.at : 0u; // lanes past the end read the queue's first record and drop the result
         j.o4 = q_o[2 * (size_t)at];
         j.d4 = q_d[2 * (size_t)at];
         return j;
     };
     uint32_t job = blockIdx.x;
     if (job >= n_jobs) return;
-    Job next = fetch(job);
-    while (job < n_jobs) {
-        const Job cur = next;
+    Where where = locate(job);
+    Job cur = request(where);
+    job += gridDim.x;
+    bool more = job < n_jobs;
+    if (more) where = locate(job);
+    for (;;) {
+        Job next = cur;
+        if (more) next = request(where);
         job += gridDim.x;
-        if (job < n_jobs) next = fetch(job);
+        const bool more_after = more && job < n_jobs;
+        if (more_after) where = locate(job);
         Nearest best = nearest_init(cur.d4.w);
         const uint32_t first = cur.cluster * cluster_pairs;
         scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), cur.o4.x, cur.o4.y, cur.o4.z, cur.d4.x, cur.d4.y, cur.d4.z, best);
@@ -520,6 +541,9 @@ __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__
             const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | tri_orig[best.index];
             atomicMin(&hit[__float_as_uint(cur.o4.w)], key);
         }
+        if (!more) break;
+        cur = next;
+        more = more_after;
     }
 }
 
