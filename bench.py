@@ -194,10 +194,10 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             # Steps just enqueue: consecutive frames overlap on the device (a stream per frame in flight), and with
-            # N > 1 so do the all-reduce of one frame and the kernels of the next.  Every 16th step
+            # N > 1 so do the all-reduce of one frame and the kernels of the next.  Every 32nd step
             # is a sampling step: the device is drained first, so that the frame runs alone and the
             # HIP events around its triangle kernels time them undisturbed; its counters are read back.
-            sampling = i % 16 == 0
+            sampling = i % 32 == 0
             if sampling:
                 torch.cuda.synchronize()
             renderer.want_stats = sampling
