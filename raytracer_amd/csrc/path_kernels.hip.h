@@ -497,17 +497,25 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DeviceScene sc, Work w, F
     if (pixel >= f.n_pixels) return;
     float4 acc = sum[f.pixel_offset + pixel];
     const uint32_t n_samples = f.n_paths / f.n_pixels;
-    for (uint32_t s = 0; s < n_samples; s++) {
-        const uint32_t p = s * f.n_pixels + pixel;
-        const float4 rad = w.rad[p];
-        const uint32_t flags = __float_as_uint(rad.w);
-        V3 L = mk(rad.x, rad.y, rad.z);
-        if (flags & F_PENDING) L = settle_pending(sc, w, f.n_paths, p, L);
-        acc.x += L.x;
-        acc.y += L.y;
-        acc.z += L.z;
-        acc.w += 1.f;
-        if (!f.indirect && (flags & F_EARLY)) break;
+    // four records are requested at a time (the additions themselves stay in sample order)
+    bool done = false;
+    for (uint32_t s0 = 0; s0 < n_samples && !done; s0 += 4) {
+        float4 rads[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) rads[k] = w.rad[(size_t)min(s0 + k, n_samples - 1) * f.n_pixels + pixel];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            if (done || s0 + k >= n_samples) break;
+            const uint32_t p = (s0 + k) * f.n_pixels + pixel;
+            const uint32_t flags = __float_as_uint(rads[k].w);
+            V3 L = mk(rads[k].x, rads[k].y, rads[k].z);
+            if (flags & F_PENDING) L = settle_pending(sc, w, f.n_paths, p, L);
+            acc.x += L.x;
+            acc.y += L.y;
+            acc.z += L.z;
+            acc.w += 1.f;
+            if (!f.indirect && (flags & F_EARLY)) done = true;
+        }
     }
     sum[f.pixel_offset + pixel] = acc;
 }
