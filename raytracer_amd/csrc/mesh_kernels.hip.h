@@ -313,6 +313,15 @@ __device__ __forceinline__ SlabRay slab_ray(float4 o4, float4 d4) {
     // +-inf for an axis-parallel ray
     r.ix = __builtin_amdgcn_rcpf(d4.x); r.iy = __builtin_amdgcn_rcpf(d4.y); r.iz = __builtin_amdgcn_rcpf(d4.z);
     r.ox = o4.x * r.ix; r.oy = o4.y * r.iy; r.oz = o4.z * r.iz;
+    // A ray (nearly) parallel to a slab has an infinite origin term, and bound * (1/u) - inf is -inf
+    // for BOTH bounds of a box that straddles zero: the box would be dropped although the ray runs
+    // inside the slab.  Such an axis is taken out of the test instead: with a NaN origin term both
+    // slab parameters are NaN, which the minimum / maximum of the three axes ignore.  (The ray may
+    // then pass outside the slab; the filter only has to keep every box a ray can hit.)
+    const float nan = __uint_as_float(0x7fc00000u);
+    if (!(fabsf(r.ox) < INFINITY)) r.ox = nan;
+    if (!(fabsf(r.oy) < INFINITY)) r.oy = nan;
+    if (!(fabsf(r.oz) < INFINITY)) r.oz = nan;
     r.cutoff = d4.w;
     return r;
 }
@@ -321,8 +330,9 @@ __device__ __forceinline__ SlabRay slab_ray(float4 o4, float4 d4) {
 // <= 16: bit 2(k - first) + h of bits[i] is set when ray i enters box h of
 // pair k before its cut-off distance.  The slab parameters come from packed
 // FMAs (t = bound * (1/u) - origin * (1/u)); this is only a filter and need not
-// follow the reference's rounding.  NaN (inf - inf on an axis-parallel ray) is
-// dropped by the minimum / maximum, which errs towards "touches".  The box
+// follow the reference's rounding.  NaN parameters (the axes slab_ray took out
+// of the test, or 0 * inf) are dropped by the minimum / maximum: that axis does
+// not constrain the ray, which errs towards "touches".  The box
 // data of an iteration (scalar loads) serves all R rays.
 template <int R>
 __device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint32_t first, uint32_t last, const SlabRay (&ray)[R],

@@ -152,3 +152,37 @@ def test_other_cluster_sizes_give_the_same_image(pairs, monkeypatch):
     t, sid, tid, abg = dev.cast(opt, o, d)
     rt_, rsid, rtid, rabg = ob.cast(desc, ob.from_rt_options(opt), o, d)
     assert np.array_equal(tid, rtid) and same_bits(t, rt_)
+
+
+@pytest.mark.parametrize("pairs", ["8", "64", "1000"])
+def test_axis_parallel_rays_through_the_cluster_filter(pairs, monkeypatch):
+    """Rays with one or two exactly-zero direction components, cast without the object boxes, so that
+    they reach the cluster filter: origins on both sides of zero on the parallel axes, inside and
+    outside the slabs of clusters that straddle zero.  8 pairs per cluster give the cat more than 64
+    clusters (two filter levels), 64 fewer (one level), 1000 two clusters."""
+    monkeypatch.setenv("RT_AMD_CLUSTER_PAIRS", pairs)
+    s = load("mesh_scene")
+    desc, cam = s.describe()
+    dev = s.upload()
+    g = np.linspace(-14, 16, 61, dtype=np.float32)
+    o, d = [], []
+    for a in g:
+        for b in g[::2]:
+            o += [[a, b, 40], [a, b, -40], [40, a, b], [-40, a, b], [a, 40, b], [a, -40, b]]
+            d += [[0, 0, -1], [0, 0, 1], [-1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 1, 0]]
+            # one zero component, the other two oblique
+            o += [[a, b, 40], [40, a, b], [a, 40, b]]
+            d += [[0, 0.6, -0.8], [-0.8, 0, 0.6], [0.6, -0.8, 0]]
+    o, d = np.array(o, np.float32), np.array(d, np.float32)
+    opt = rt.make_options(bounding_box=False, cluster_culling=True)
+    t, sid, tid, abg = dev.cast(opt, o, d)
+    te, side, tide, abge = dev.cast(rt.make_options(bounding_box=False, cluster_culling=False), o, d)
+    rt_, rsid, rtid, rabg = ob.cast(desc, ob.from_rt_options(opt), o, d)
+    assert (rtid >= 0).sum() > 500  # many of them do hit the cat
+    assert np.array_equal(tide, rtid) and same_bits(te, rt_)
+    assert np.array_equal(tid, rtid), f"{(tid != rtid).sum()} rays lose or change their triangle under culling"
+    assert np.array_equal(sid, rsid) and same_bits(t, rt_)
+    assert same_bits(abg[rtid >= 0], rabg[rtid >= 0])
+    # the same rays as shadow segments
+    vis = dev.visible(opt, o, o + 100 * d)
+    assert np.array_equal(vis, ob.visible(desc, ob.from_rt_options(opt), o, o + 100 * d))
