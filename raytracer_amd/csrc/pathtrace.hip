@@ -69,16 +69,23 @@ extern "C" const char* rt_last_error(void) { return g_error; }
 
 // ------------------------------------------------------------- host side
 
+// The work buffers of one batch in flight: path state, ray queue, live lists, counters and cluster
+// lists, all carved from ONE block of device memory (layout_work).
+struct WorkSet {
+    Work w{};
+    uint32_t paths = 0;        // batches of up to this many paths fit
+    uint32_t n_counters = 0;   // ... with up to this many triangle stages
+    uint32_t tiles = 1;        // cluster-list tiles per triangle stage
+    size_t counter_words = 0;  // queue, live, cluster and group counters: one block starting at w.q_count
+    size_t bytes = 0;          // size of the block
+};
+
 struct rt_scene {
     DeviceScene d{};
     std::vector<void*> allocations;
     // batch work buffers, grown on demand
-    Work w{};
-    std::vector<void*> work_allocations;
-    uint32_t work_paths = 0;
-    uint32_t n_counters = 0;
-    uint32_t tiles = 1;                  // cluster-list tiles per k_mesh stage
-    size_t counter_words = 0;            // queue, cluster and group counters: one block starting at w.q_count
+    WorkSet ws{};
+    void* work_block = nullptr;
     std::vector<uint32_t> cluster_tris;  // triangles per culling cluster
     // profiling events
     std::vector<hipEvent_t> events;   // pool, reused by every call
@@ -154,27 +161,29 @@ int check_frame(const rt_scene* scene, const rt_camera* cam, const rt_options* o
 }
 
 void free_work(rt_scene* s) {
-    for (void* p : s->work_allocations) (void)hipFree(p);
-    s->work_allocations.clear();
-    s->work_paths = 0;
-    s->n_counters = 0;
-    std::memset(&s->w, 0, sizeof s->w);
+    if (s->work_block) (void)hipFree(s->work_block);
+    s->work_block = nullptr;
+    s->ws = WorkSet{};
 }
 
-template <typename T>
-int work_alloc(rt_scene* s, T** out, size_t count) {
-    void* dev = nullptr;
-    HIP_TRY(hipMalloc(&dev, (count ? count : 1) * sizeof(T)));
-    s->work_allocations.push_back(dev);
-    *out = static_cast<T*>(dev);
-    return RT_OK;
-}
+// Hands out consecutive 256-byte aligned pieces of a block; with a null base it only adds up sizes.
+struct Carver {
+    unsigned char* base;
+    size_t used = 0;
+    template <typename T>
+    T* take(size_t count) {
+        used = (used + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + used) : nullptr;
+        used += (count ? count : 1) * sizeof(T);
+        return p;
+    }
+};
 
-// Work buffers for batches of up to n_paths paths and max_depth bounces.
-int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
-    if (s->work_paths >= n_paths && s->n_counters >= n_counters) return RT_OK;
-    free_work(s);
-    const size_t nl = s->d.n_lights ? s->d.n_lights : 1;
+// Lays the work buffers for batches of up to n_paths paths and n_counters triangle stages out in
+// `arena` (null: only ws->bytes and the capacities are computed).  The cluster lists get at most
+// list_budget bytes; a triangle stage is cut into tiles of rays when that does not cover the queue.
+int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, size_t list_budget, unsigned char* arena, WorkSet* ws) {
+    const size_t nl = d.n_lights ? d.n_lights : 1;
     // a shard receives the rays of every kShards-th wavefront of a path kernel
     // (k_shade walks its list of live paths shard by shard, every shard ending in a partial workgroup:
     // up to kShards workgroups more than the paths need)
@@ -188,14 +197,12 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t queue_entries = shard_capacity * kShards;
     if (queue_entries > 0xffffffffu) { rt_set_error("batch too large for the ray queue"); return RT_ERR_INVALID; }
     // cluster lists: one tile of rays at a time if the whole queue would not fit the budget
-    const size_t nc = s->d.n_clusters, ng = s->d.n_groups;
+    const size_t nc = d.n_clusters, ng = d.n_groups;
     size_t list_capacity = 0, tiles = 1;
     if (nc > 1) {
         // a tile is a range of 256-ray blocks; every shard may end in a partial block
         const size_t max_blocks = ((shard_capacity + kBlock - 1) / kBlock) * kShards;
-        size_t budget = kClusterListBudget, free_bytes = 0, total_bytes = 0;
-        if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && free_bytes / 4 < budget) budget = free_bytes / 4;
-        list_capacity = budget / (4 * (nc + ng)) / kBlock * kBlock;
+        list_capacity = list_budget / (4 * (nc + ng)) / kBlock * kBlock;
         if (list_capacity > max_blocks * kBlock) list_capacity = max_blocks * kBlock;
         if (list_capacity < kBlock) list_capacity = kBlock;
         tiles = (max_blocks + list_capacity / kBlock - 1) / (list_capacity / kBlock);
@@ -204,36 +211,62 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     const size_t q_words = (size_t)n_counters * kShards * kCountStride;
     const size_t cl_words = slots_cl * nc * kCountStride, grp_words = slots_cl * ng * kCountStride;
     const size_t live_capacity = ((n_waves + kShards - 1) / kShards) * 64; // a wavefront keeps at most its 64 paths
-    int rc;
     const size_t live_total = kShards * live_capacity; // >= n_paths: buffer 0 also holds the camera rays at the paths' own indices
     if (2 * live_total + (size_t)n_paths * nl > 0xffffffffu) { rt_set_error("batch too large for 32-bit hit slots"); return RT_ERR_INVALID; }
-    float4* rays = nullptr;   // (ray_o, ray_d) records, two buffers of live_total
-    if ((rc = work_alloc(s, &rays, 4 * live_total)) || (rc = work_alloc(s, &s->w.thr, 2 * live_total)) ||
-        (rc = work_alloc(s, &s->w.rad, n_paths)) ||
-        (rc = work_alloc(s, &s->w.pend, (size_t)n_paths * nl)) || (rc = work_alloc(s, &s->w.hit, 2 * live_total + (size_t)n_paths * nl)) ||
-        (rc = work_alloc(s, &s->w.q_o, 2 * queue_entries)) ||
-        (rc = work_alloc(s, &s->w.q_count, 2 * q_words + cl_words + grp_words)) || // one block: cleared with one fill
-        (rc = work_alloc(s, &s->w.live, 2 * kShards * live_capacity)) ||
-        (rc = work_alloc(s, &s->w.cast_count, (size_t)n_counters * kCastShards * kCountStride)) ||
-        (rc = work_alloc(s, &s->w.cl_list, nc * list_capacity)) ||
-        (rc = work_alloc(s, &s->w.grp_list, ng * list_capacity))) {
-        free_work(s);
+    Carver c{arena};
+    Work& w = ws->w;
+    float4* rays = c.take<float4>(4 * live_total); // (ray_o, ray_d) records, two buffers of live_total
+    w.ray_o.base = rays;
+    w.ray_d.base = rays + 1;
+    w.thr = c.take<float4>(2 * live_total);
+    w.rad = c.take<float4>(n_paths);
+    w.pend = c.take<float4>((size_t)n_paths * nl);
+    w.hit = c.take<unsigned long long>(2 * live_total + (size_t)n_paths * nl);
+    w.q_o = c.take<float4>(2 * queue_entries);
+    w.q_d = w.q_o + 1;
+    w.q_count = c.take<uint32_t>(2 * q_words + cl_words + grp_words); // one block: cleared with one fill
+    w.live_count = w.q_count + q_words;
+    w.cl_count = w.live_count + q_words;
+    w.grp_count = w.cl_count + cl_words;
+    w.live = c.take<uint32_t>(2 * kShards * live_capacity);
+    w.cast_count = c.take<uint32_t>((size_t)n_counters * kCastShards * kCountStride);
+    w.cl_list = c.take<uint32_t>(nc * list_capacity);
+    w.grp_list = c.take<uint32_t>(ng * list_capacity);
+    w.live_total = (uint32_t)live_total;
+    w.live_capacity = (uint32_t)live_capacity;
+    w.shard_capacity = (uint32_t)shard_capacity;
+    w.list_capacity = (uint32_t)list_capacity;
+    ws->counter_words = 2 * q_words + cl_words + grp_words;
+    ws->tiles = (uint32_t)tiles;
+    ws->paths = n_paths;
+    ws->n_counters = n_counters;
+    ws->bytes = c.used;
+    return RT_OK;
+}
+
+// The scene's own work buffers for batches of up to n_paths paths and n_counters triangle stages.
+int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
+    if (s->ws.paths >= n_paths && s->ws.n_counters >= n_counters) return RT_OK;
+    n_paths = std::max(n_paths, s->ws.paths);          // never shrink one dimension to grow the other
+    n_counters = std::max(n_counters, s->ws.n_counters);
+    free_work(s);
+    size_t budget = kClusterListBudget, free_bytes = 0, total_bytes = 0;
+    if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && free_bytes / 4 < budget) budget = free_bytes / 4;
+    WorkSet ws;
+    int rc = layout_work(s->d, n_paths, n_counters, budget, nullptr, &ws);
+    if (rc != RT_OK) return rc;
+    void* block = nullptr;
+    if (hipMalloc(&block, ws.bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        rt_set_error("out of device memory: %zu bytes of work buffers for batches of %u paths", ws.bytes, n_paths);
+        return RT_ERR_NOMEM;
+    }
+    if ((rc = layout_work(s->d, n_paths, n_counters, budget, static_cast<unsigned char*>(block), &ws)) != RT_OK) {
+        (void)hipFree(block);
         return rc;
     }
-    s->w.ray_o.base = rays;
-    s->w.ray_d.base = rays + 1;
-    s->w.live_total = (uint32_t)live_total;
-    s->w.q_d = s->w.q_o + 1;
-    s->w.live_count = s->w.q_count + q_words;
-    s->w.cl_count = s->w.live_count + q_words;
-    s->w.grp_count = s->w.cl_count + cl_words;
-    s->counter_words = 2 * q_words + cl_words + grp_words;
-    s->w.live_capacity = (uint32_t)live_capacity;
-    s->w.shard_capacity = (uint32_t)shard_capacity;
-    s->w.list_capacity = (uint32_t)list_capacity;
-    s->tiles = (uint32_t)tiles;
-    s->work_paths = n_paths;
-    s->n_counters = n_counters;
+    s->work_block = block;
+    s->ws = ws;
     return RT_OK;
 }
 
@@ -272,18 +305,19 @@ int mark_event(rt_scene* s, hipStream_t stream, char tag) {
 
 // One k_mesh stage: the queued rays of `counter` against the mesh, either by
 // the exhaustive scan or through the cluster lists.
-int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile, bool cull, uint32_t batch_paths) {
+int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t stream, bool profile, bool cull, uint32_t batch_paths) {
+    const Work& w = ws.w;
     if (s->d.n_triangles == 0) return RT_OK;
     auto mark = [&](char tag) -> int { return profile ? mark_event(s, stream, tag) : RT_OK; };
     int rc;
     const f2* tri2 = reinterpret_cast<const f2*>(s->d.tri_pair);
-    const uint32_t* q_count = s->w.q_count + (size_t)counter * kShards * kCountStride;
+    const uint32_t* q_count = w.q_count + (size_t)counter * kShards * kCountStride;
     if (cull && s->d.n_clusters > 1) {
         const uint32_t nc = s->d.n_clusters;
-        const uint32_t blocks_per_tile = s->w.list_capacity / kBlock;
-        for (uint32_t tile = 0; tile < s->tiles; tile++) {
-            const size_t slot = (size_t)counter * s->tiles + tile;
-            uint32_t* cl_count = s->w.cl_count + slot * nc * kCountStride;
+        const uint32_t blocks_per_tile = w.list_capacity / kBlock;
+        for (uint32_t tile = 0; tile < ws.tiles; tile++) {
+            const size_t slot = (size_t)counter * ws.tiles + tile;
+            uint32_t* cl_count = w.cl_count + slot * nc * kCountStride;
             if ((rc = mark('B')) != RT_OK) return rc;
             const f2* cl_pair = reinterpret_cast<const f2*>(s->d.cl_pair);
             // two ray blocks per workgroup, except for short batches (measured: better from about 2 M paths up)
@@ -302,29 +336,29 @@ int launch_mesh(rt_scene* s, uint32_t counter, hipStream_t stream, bool profile,
             auto bin64 = wider ? k_bin64<4> : wide ? k_bin64<2> : k_bin64<1>;
             if (s->d.n_groups == 0) {
                 hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, cl_pair, nc,
-                                   (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
-                                   tile * blocks_per_tile, blocks_per_tile, cl_count, s->w.cl_list, s->w.list_capacity);
+                                   (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
+                                   tile * blocks_per_tile, blocks_per_tile, cl_count, w.cl_list, w.list_capacity);
             } else {
                 const uint32_t ng = s->d.n_groups;
-                uint32_t* grp_count = s->w.grp_count + slot * ng * kCountStride;
+                uint32_t* grp_count = w.grp_count + slot * ng * kCountStride;
                 hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
-                                   (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity,
-                                   tile * blocks_per_tile, blocks_per_tile, grp_count, s->w.grp_list, s->w.list_capacity);
+                                   (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
+                                   tile * blocks_per_tile, blocks_per_tile, grp_count, w.grp_list, w.list_capacity);
                 auto bin_groups = wider ? k_bin_groups<4> : wide ? k_bin_groups<2> : k_bin_groups<1>;
                 hipLaunchKernelGGL(bin_groups, dim3(bin_grid), dim3(kBlock), 0, stream, cl_pair, nc, ng, s->d.group_clusters,
-                                   (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)grp_count,
-                                   (const uint32_t*)s->w.grp_list, cl_count, s->w.cl_list, s->w.list_capacity);
+                                   (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)grp_count,
+                                   (const uint32_t*)w.grp_list, cl_count, w.cl_list, w.list_capacity);
             }
             if ((rc = mark('M')) != RT_OK) return rc;
             hipLaunchKernelGGL(k_mesh_clusters, dim3(cl_grid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
-                               s->d.cluster_pairs, (const float4*)s->w.q_o, (const float4*)s->w.q_d, (const uint32_t*)cl_count,
-                               (const uint32_t*)s->w.cl_list, s->w.list_capacity, s->w.hit);
+                               s->d.cluster_pairs, (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)cl_count,
+                               (const uint32_t*)w.cl_list, w.list_capacity, w.hit);
             if ((rc = mark('E')) != RT_OK) return rc;
         }
     } else {
         if ((rc = mark('M')) != RT_OK) return rc;
         hipLaunchKernelGGL(k_mesh, dim3(kMeshGrid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles,
-                           (const float4*)s->w.q_o, (const float4*)s->w.q_d, q_count, s->w.shard_capacity, s->w.hit);
+                           (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity, w.hit);
         if ((rc = mark('E')) != RT_OK) return rc;
     }
     HIP_TRY(hipGetLastError());
@@ -557,34 +591,41 @@ extern "C" int rt_accumulate(rt_scene* s, const rt_camera* cam, const rt_options
     return rt_accumulate_rows(s, cam, opt, sample_begin, sample_end, 0, cam ? cam->height : 0, d_sum, stream_, stats);
 }
 
-extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin,
-                                  uint32_t sample_end, uint32_t row_begin, uint32_t row_end, float* d_sum, void* stream_,
-                                  rt_stats* stats) {
-    int rc = check_frame(s, cam, opt);
-    if (rc != RT_OK) return rc;
-    if (!d_sum || sample_end < sample_begin) { rt_set_error("rt_accumulate: bad sample range or null buffer"); return RT_ERR_INVALID; }
-    if (row_end < row_begin || row_end > cam->height) { rt_set_error("rt_accumulate_rows: rows [%u, %u) of %u", row_begin, row_end, cam->height); return RT_ERR_INVALID; }
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+namespace {
+
+// Rows per chunk and samples per batch of a band of `rows` rows, for batches of at most max_paths
+// paths: a band of more pixels than that is rendered in chunks of rows, and a chunk in batches of samples.
+struct BatchShape {
+    uint32_t rows_per_chunk, per_batch;
+};
+
+BatchShape batch_shape(uint32_t width, uint32_t rows, uint32_t n_samples, uint32_t max_paths) {
+    BatchShape b;
+    b.rows_per_chunk = std::max(1u, std::min(rows, max_paths / width));
+    b.per_batch = std::max(1u, max_paths / (b.rows_per_chunk * width));
+    if (b.per_batch > n_samples) b.per_batch = n_samples;
+    return b;
+}
+
+// The body of rt_accumulate_rows on a given set of work buffers, which must hold batches of
+// shape.rows_per_chunk * width * shape.per_batch paths with max_depth + 1 triangle stages.
+// With stats == nullptr and no progress callback it only enqueues work and allocates nothing.
+int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const rt_camera* cam, const rt_options* opt,
+                       uint32_t sample_begin, uint32_t sample_end, uint32_t row_begin, uint32_t row_end, float* d_sum,
+                       hipStream_t stream, rt_stats* stats, bool report_progress) {
+    int rc;
+    const Work& w = ws.w;
     Frame f = make_frame(cam, opt);
-    if (stats) std::memset(stats, 0, sizeof *stats);
     const uint32_t n_samples = sample_end - sample_begin;
-    if (row_end == row_begin || n_samples == 0) return RT_OK;
-    // A batch is at most 2^24 paths: a band of more pixels than that is rendered in chunks of rows,
-    // and a chunk in batches of samples.
-    const uint32_t rows_per_chunk = std::max(1u, std::min(row_end - row_begin, kMaxPathsPerBatch / cam->width));
-    const uint32_t chunk_pixels = rows_per_chunk * cam->width;
-    uint32_t per_batch = kMaxPathsPerBatch / chunk_pixels;
-    if (per_batch == 0) per_batch = 1;
-    if (per_batch > n_samples) per_batch = n_samples;
+    const uint32_t rows_per_chunk = shape.rows_per_chunk, per_batch = shape.per_batch;
     const uint32_t n_counters = (uint32_t)opt->max_depth + 1u;
-    if ((rc = ensure_work(s, per_batch * chunk_pixels, n_counters)) != RT_OK) return rc;
     const uint64_t total_paths = (uint64_t)n_samples * (row_end - row_begin) * cam->width;
 
     const bool profile = stats && opt->profile;
     f.count_casts = stats != nullptr;
     const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
     f.prune_zero_terms = opt->cluster_culling != 0;
-    const size_t cl_words = cull ? (size_t)n_counters * s->tiles * s->d.n_clusters * kCountStride : 0;
+    const size_t cl_words = cull && stats ? (size_t)n_counters * ws.tiles * s->d.n_clusters * kCountStride : 0;
     std::vector<uint32_t> cl_counts(cl_words);
     uint64_t tests = 0;
     s->event_tags.clear();
@@ -593,7 +634,7 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
         if (!s->frame_end) HIP_TRY(hipEventCreate(&s->frame_end));
         HIP_TRY(hipEventRecord(s->frame_begin, stream));
     }
-    std::vector<uint32_t> counts((size_t)n_counters * kShards * kCountStride);
+    std::vector<uint32_t> counts(stats ? (size_t)n_counters * kShards * kCountStride : 0);
     std::vector<uint32_t> cast_counts(stats ? (size_t)n_counters * kCastShards * kCountStride : 0);
     uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
     uint32_t batches = 0;
@@ -607,37 +648,37 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
         f.n_paths = in_batch * n_pixels;
         f.sample_begin = sample_begin + first;
         const dim3 grid((f.n_paths + kBlock - 1) / kBlock), block(kBlock);
-        HIP_TRY(hipMemsetAsync(s->w.q_count, 0, s->counter_words * sizeof(uint32_t), stream));
-        if (stats) HIP_TRY(hipMemsetAsync(s->w.cast_count, 0, cast_counts.size() * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(w.q_count, 0, ws.counter_words * sizeof(uint32_t), stream));
+        if (stats) HIP_TRY(hipMemsetAsync(w.cast_count, 0, cast_counts.size() * sizeof(uint32_t), stream));
         // paths per lane: as many as still leave 2 048 workgroups (8 per CU)
         if (f.n_paths >= 2048u * kBlock * 4)
-            hipLaunchKernelGGL(k_generate<4>, dim3((f.n_paths + kBlock * 4 - 1) / (kBlock * 4)), block, 0, stream, s->d, s->w, f);
+            hipLaunchKernelGGL(k_generate<4>, dim3((f.n_paths + kBlock * 4 - 1) / (kBlock * 4)), block, 0, stream, s->d, w, f);
         else if (f.n_paths >= 2048u * kBlock * 2)
-            hipLaunchKernelGGL(k_generate<2>, dim3((f.n_paths + kBlock * 2 - 1) / (kBlock * 2)), block, 0, stream, s->d, s->w, f);
+            hipLaunchKernelGGL(k_generate<2>, dim3((f.n_paths + kBlock * 2 - 1) / (kBlock * 2)), block, 0, stream, s->d, w, f);
         else
-            hipLaunchKernelGGL(k_generate<1>, grid, block, 0, stream, s->d, s->w, f);
+            hipLaunchKernelGGL(k_generate<1>, grid, block, 0, stream, s->d, w, f);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
-            if ((rc = launch_mesh(s, (uint32_t)depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
+            if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_shade, depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, s->w, f, depth);
+            hipLaunchKernelGGL(k_shade, depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
         }
-        if ((rc = launch_mesh(s, (uint32_t)opt->max_depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
-        hipLaunchKernelGGL(k_accumulate, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, s->d, s->w, f,
+        if ((rc = launch_mesh(s, ws, (uint32_t)opt->max_depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_accumulate, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, s->d, w, f,
                            reinterpret_cast<float4*>(d_sum));
         HIP_TRY(hipGetLastError());
         batches++;
         paths += f.n_paths;
-        if (s->progress) {
+        if (report_progress && s->progress) {
             HIP_TRY(hipStreamSynchronize(stream));
             s->progress(paths, total_paths, s->progress_user);
         }
         if (stats) { // the counters are reused by the next batch: read them now
-            HIP_TRY(hipMemcpyAsync(counts.data(), s->w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipMemcpyAsync(cast_counts.data(), s->w.cast_count, cast_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), s->w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(counts.data(), w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(cast_counts.data(), w.cast_count, cast_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             uint64_t batch_rays = 0;
             for (size_t i = 0; i < counts.size(); i += kCountStride) batch_rays += counts[i];
@@ -677,6 +718,31 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
         stats->sphere_casts = sphere_casts;
     }
     return RT_OK;
+}
+
+int check_accumulate(const rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin, uint32_t sample_end,
+                     uint32_t row_begin, uint32_t row_end, const float* d_sum) {
+    int rc = check_frame(s, cam, opt);
+    if (rc != RT_OK) return rc;
+    if (!d_sum || sample_end < sample_begin) { rt_set_error("rt_accumulate: bad sample range or null buffer"); return RT_ERR_INVALID; }
+    if (row_end < row_begin || row_end > cam->height) { rt_set_error("rt_accumulate_rows: rows [%u, %u) of %u", row_begin, row_end, cam->height); return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin,
+                                  uint32_t sample_end, uint32_t row_begin, uint32_t row_end, float* d_sum, void* stream_,
+                                  rt_stats* stats) {
+    int rc = check_accumulate(s, cam, opt, sample_begin, sample_end, row_begin, row_end, d_sum);
+    if (rc != RT_OK) return rc;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (row_end == row_begin || sample_end == sample_begin) return RT_OK;
+    // A batch is at most 2^24 paths.
+    const BatchShape shape = batch_shape(cam->width, row_end - row_begin, sample_end - sample_begin, kMaxPathsPerBatch);
+    if ((rc = ensure_work(s, shape.per_batch * shape.rows_per_chunk * cam->width, (uint32_t)opt->max_depth + 1u)) != RT_OK) return rc;
+    return accumulate_batches(s, s->ws, shape, cam, opt, sample_begin, sample_end, row_begin, row_end, d_sum,
+                              static_cast<hipStream_t>(stream_), stats, true);
 }
 
 extern "C" int rt_resolve(const float* d_sum, uint32_t n_pixels, float* d_out_rgb, void* stream_) {
@@ -726,6 +792,7 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
     if (n > kMaxPathsPerBatch) { rt_set_error("probe: at most %u rays per call", kMaxPathsPerBatch); return RT_ERR_INVALID; }
     int rc = ensure_work(s, n, 2);
     if (rc != RT_OK) return rc;
+    const Work& w = s->ws.w;
     rt_camera cam;
     std::memset(&cam, 0, sizeof cam);
     cam.width = n;
@@ -749,13 +816,13 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
     rc = RT_OK;
     do {
         if (hipMemcpy(d_a, a, 3 * (size_t)n * 4, hipMemcpyHostToDevice) || hipMemcpy(d_b, b, 3 * (size_t)n * 4, hipMemcpyHostToDevice) ||
-            hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(s->w.q_count, 0, 2 * kShards * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
-        hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, s->w, f, (const float*)d_a, (const float*)d_b, as_segments);
+            hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(w.q_count, 0, 2 * kShards * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, w, f, (const float*)d_a, (const float*)d_b, as_segments);
         const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
-        if (cull && hipMemset(s->w.cl_count, 0, (size_t)2 * s->tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
-        if (cull && s->d.n_groups && hipMemset(s->w.grp_count, 0, (size_t)2 * s->tiles * s->d.n_groups * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
-        if (launch_mesh(s, 0, nullptr, false, cull, n) != RT_OK) { rc = RT_ERR_DEVICE; break; }
-        hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, s->w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
+        if (cull && hipMemset(w.cl_count, 0, (size_t)2 * s->ws.tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        if (cull && s->d.n_groups && hipMemset(w.grp_count, 0, (size_t)2 * s->ws.tiles * s->d.n_groups * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        if (launch_mesh(s, s->ws, 0, nullptr, false, cull, n) != RT_OK) { rc = RT_ERR_DEVICE; break; }
+        hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }
         if (as_segments) {
             if (hipMemcpy(out_visible, d_v, (size_t)n * 4, hipMemcpyDeviceToHost)) rc = RT_ERR_DEVICE;
