@@ -154,6 +154,23 @@ int rt_accumulate_rows(rt_scene* scene, const rt_camera* cam, const rt_options* 
                        uint32_t sample_begin, uint32_t sample_end, uint32_t row_begin,
                        uint32_t row_end, float* d_sum, void* stream, rt_stats* stats);
 
+/* rt_accumulate for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It
+ * has no counterpart in the reference.  The work buffers rt_accumulate takes
+ * from hipMalloc come from a 64 MiB device array of the library instead (every
+ * GPU the library runs on holds its copy until the process ends), so the frame
+ * is rendered in more, smaller batches -- a few ten thousand paths each; the
+ * sums are the ones rt_accumulate produces, bit for bit.  The call issues no
+ * hipMalloc / hipFree and only enqueues work on `stream`; it takes no
+ * statistics and reports no progress.  RT_ERR_INVALID when a single image row
+ * of the frame does not fit the array (several hundred thousand pixels wide,
+ * or a scene with very many lights or clusters).  Call rt_init on the device
+ * first (it resolves the array's address there; otherwise the first call
+ * does).  All calls on one GPU share the array: calls that overlap on a GPU --
+ * from several threads, streams or scene handles -- race. */
+int rt_accumulate_static(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
+                         uint32_t sample_begin, uint32_t sample_end, float* d_sum, void* stream);
+
 /* Replaces the reference's progress bar (src/raytrace.cu:601-627, a mapped
  * counter the host polls while the kernel runs).  A frame is rendered in
  * batches of at most 2^24 paths; when a callback is set, rt_accumulate and

@@ -125,6 +125,7 @@ def _load() -> C.CDLL:
         "rt_accumulate": [vp, C.POINTER(Camera), C.POINTER(Options), C.c_uint32, C.c_uint32, vp, vp, C.POINTER(Stats)],
         "rt_accumulate_rows": [vp, C.POINTER(Camera), C.POINTER(Options), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp,
                                C.POINTER(Stats)],
+        "rt_accumulate_static": [vp, C.POINTER(Camera), C.POINTER(Options), C.c_uint32, C.c_uint32, vp, vp],
         "rt_resolve": [vp, C.c_uint32, vp, vp],
         "rt_cast": [vp, C.POINTER(Options), C.c_uint32, _f32p, _f32p, _f32p, _i32p, _i32p, _f32p],
         "rt_visible": [vp, C.POINTER(Options), C.c_uint32, _f32p, _f32p, _i32p],
@@ -168,6 +169,7 @@ EXPORTS = [
     "rt_host_scene_set_num_rays", "rt_host_scene_add_sphere", "rt_host_scene_add_object", "rt_host_scene_add_light",
     "rt_host_scene_set_options", "rt_host_scene_render", "rt_host_scene_describe", "rt_host_scene_image",
     "rt_write_png", "rt_write_pfm", "rt_set_progress", "rt_host_scene_render_frames", "rt_accumulate_rows",
+    "rt_accumulate_static",
 ]
 
 
@@ -280,6 +282,12 @@ class DeviceScene:
         _check(lib.rt_accumulate_rows(self._h, C.byref(cam), C.byref(opt), sample_begin, sample_end, row_begin, row_end,
                                       C.c_void_p(d_sum_ptr), C.c_void_p(stream), C.byref(st) if st is not None else None))
         return st
+
+    def accumulate_static(self, cam: Camera, opt: Options, sample_begin: int, sample_end: int, d_sum_ptr: int,
+                          stream: int = 0) -> None:
+        """rt_accumulate_static: the same sums from the library's fixed work area, without any device allocation."""
+        _check(lib.rt_accumulate_static(self._h, C.byref(cam), C.byref(opt), sample_begin, sample_end,
+                                        C.c_void_p(d_sum_ptr), C.c_void_p(stream)))
 
     def set_progress(self, callback) -> None:
         """callback(paths_done, paths_total) after every finished batch of a frame; None removes it."""

@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -367,12 +368,48 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
 
 } // namespace
 
+// ---- rt_accumulate_static: the same frame on a fixed work area -------------
+//
+// For callers that may not allocate device memory (code under HIP graph capture, serving loops,
+// harnesses that forbid it): the work buffers rt_accumulate takes from hipMalloc come from one
+// file-scope device array instead.  Every GPU the library runs on holds its own copy of the array,
+// at its own address, until the process ends; the name `scratch` is only a host-side stand-in, so
+// host code uses the address hipGetSymbolAddress returns for the current device and nothing else.
+constexpr size_t kStaticWorkBytes = size_t(64) << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticWorkBytes];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+unsigned char* g_static_work[kMaxDevices]; // device address of `scratch` per device, once resolved
+std::mutex g_static_work_mutex;
+
+// The current device's copy of `scratch`.
+int static_work_area(unsigned char** out) {
+    int device = -1;
+    HIP_TRY(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) { rt_set_error("static work area: device %d out of range", device); return RT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(g_static_work_mutex);
+    if (!g_static_work[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) { rt_set_error("static work area: null symbol address on device %d", device); return RT_ERR_DEVICE; }
+        g_static_work[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_static_work[device];
+    return RT_OK;
+}
+
+} // namespace
+
 extern "C" int rt_init(int32_t device) {
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (device < 0 || device >= count) { rt_set_error("rt_init: device %d of %d", device, count); return RT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(device));
-    return RT_OK;
+    // set-up time: resolve this device's copy of the static work area (rt_accumulate_static)
+    unsigned char* area = nullptr;
+    return static_work_area(&area);
 }
 
 extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
@@ -743,6 +780,37 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
     if ((rc = ensure_work(s, shape.per_batch * shape.rows_per_chunk * cam->width, (uint32_t)opt->max_depth + 1u)) != RT_OK) return rc;
     return accumulate_batches(s, s->ws, shape, cam, opt, sample_begin, sample_end, row_begin, row_end, d_sum,
                               static_cast<hipStream_t>(stream_), stats, true);
+}
+
+extern "C" int rt_accumulate_static(rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin,
+                                    uint32_t sample_end, float* d_sum, void* stream_) {
+    int rc = check_accumulate(s, cam, opt, sample_begin, sample_end, 0, cam ? cam->height : 0, d_sum);
+    if (rc != RT_OK) return rc;
+    if (cam->height == 0 || sample_end == sample_begin) return RT_OK;
+    unsigned char* area = nullptr;
+    if ((rc = static_work_area(&area)) != RT_OK) return rc;
+    // The largest batch whose work buffers fit the area (at most half of it for cluster lists): the
+    // frame is rendered in as many batches of rows and samples as that takes.
+    const uint32_t n_counters = (uint32_t)opt->max_depth + 1u;
+    uint32_t max_paths = kMaxPathsPerBatch;
+    WorkSet ws;
+    BatchShape shape;
+    for (;;) {
+        shape = batch_shape(cam->width, cam->height, sample_end - sample_begin, max_paths);
+        const uint64_t n = (uint64_t)shape.per_batch * shape.rows_per_chunk * cam->width;
+        if (n <= kMaxPathsPerBatch && layout_work(s->d, (uint32_t)n, n_counters, kStaticWorkBytes / 2, nullptr, &ws) == RT_OK &&
+            ws.bytes <= kStaticWorkBytes)
+            break;
+        if (n <= cam->width) {
+            rt_set_error("rt_accumulate_static: one image row of %u pixels with this scene (%u lights, %u clusters) needs more "
+                         "than the static work area of %zu bytes", cam->width, s->d.n_lights, s->d.n_clusters, kStaticWorkBytes);
+            return RT_ERR_INVALID;
+        }
+        max_paths = (uint32_t)std::max<uint64_t>(n / 2, cam->width);
+    }
+    if ((rc = layout_work(s->d, ws.paths, n_counters, kStaticWorkBytes / 2, area, &ws)) != RT_OK) return rc;
+    return accumulate_batches(s, ws, shape, cam, opt, sample_begin, sample_end, 0, cam->height, d_sum,
+                              static_cast<hipStream_t>(stream_), nullptr, false);
 }
 
 extern "C" int rt_resolve(const float* d_sum, uint32_t n_pixels, float* d_out_rgb, void* stream_) {

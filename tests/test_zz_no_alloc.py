@@ -1,0 +1,69 @@
+"""rt_accumulate_static: the entry point that allocates nothing, against rt_accumulate.
+
+Its work buffers live in a 64 MiB device array of the library instead of hipMalloc'ed memory, so a
+frame is rendered in more and smaller batches; the sums must be the same, bit for bit, also on a
+second call with a smaller input that finds the previous call's contents in the array.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from helpers import load, variant
+from hip_mem import DeviceBuffer
+
+pytestmark = pytest.mark.gpu
+
+
+def accumulate_static(dev, cam, opt, begin, end, buf):
+    return rt.lib.rt_accumulate_static(dev._h, C.byref(cam), C.byref(opt), begin, end, C.c_void_p(buf.address), None)
+
+
+def both_ways(scene, opt, begin, end):
+    desc, cam = scene.describe()
+    dev = scene.upload()
+    n = cam.width * cam.height
+    want, got = DeviceBuffer(4 * n), DeviceBuffer(4 * n)
+    dev.accumulate(cam, opt, begin, end, want.address)
+    rc = accumulate_static(dev, cam, opt, begin, end, got)
+    assert rc == rt.RT_OK, rt.lib.rt_last_error()
+    a, b = want.to_host(), got.to_host()
+    assert a.reshape(-1, 4)[:, 3].max() == end - begin
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).reshape(-1, 4).any(axis=1).sum()} of {n} pixels differ"
+    return dev, cam, got
+
+
+def test_static_work_area_gives_the_sums_of_rt_accumulate():
+    rt.init(0)
+    # first call: two lights' worth of state per path, several batches (240 x 180 x 6 = 259 200 paths)
+    s = variant("mesh_scene", "glass", 240, 180, 6)
+    s.add_light([10, 20, 40], 4e9)
+    dev, cam, buf = both_ways(s, rt.make_options(seed=61), 0, 6)
+    # second call, smaller input, right after: it finds the first call's state in the array
+    both_ways(load("mesh_scene", 72, 40, 3), rt.make_options(seed=62), 2, 5)
+    # a scene without a mesh, direct light only, then the exhaustive scan
+    both_ways(load("default", 96, 64, 4), rt.make_options(indirect=False, seed=63), 0, 4)
+    both_ways(load("mesh_scene", 64, 48, 2), rt.make_options(seed=64, cluster_culling=False), 0, 2)
+    # continuing a sum: ranges in sample order add up to the whole
+    n = cam.width * cam.height
+    whole = DeviceBuffer(4 * n)
+    parts = DeviceBuffer(4 * n)
+    opt = rt.make_options(seed=65)
+    assert accumulate_static(dev, cam, opt, 0, 5, whole) == rt.RT_OK
+    assert accumulate_static(dev, cam, opt, 0, 2, parts) == rt.RT_OK
+    assert accumulate_static(dev, cam, opt, 2, 5, parts) == rt.RT_OK
+    assert np.array_equal(whole.to_host().view(np.uint32), parts.to_host().view(np.uint32))
+
+
+def test_static_work_area_rejects_what_does_not_fit():
+    rt.init(0)
+    s = load("mesh_scene", 1 << 20, 2, 1)  # one image row alone needs hundreds of megabytes of path state
+    desc, cam = s.describe()
+    dev = s.upload()
+    buf = DeviceBuffer(16)
+    rc = rt.lib.rt_accumulate_static(dev._h, C.byref(cam), C.byref(rt.make_options()), 0, 1, C.c_void_p(buf.address), None)
+    assert rc == rt.RT_ERR_INVALID and b"static work area" in rt.lib.rt_last_error()
+    assert rt.lib.rt_accumulate_static(None, C.byref(cam), C.byref(rt.make_options()), 0, 1, C.c_void_p(buf.address), None) == rt.RT_ERR_INVALID
+    assert rt.lib.rt_accumulate_static(dev._h, C.byref(cam), C.byref(rt.make_options()), 0, 1, None, None) == rt.RT_ERR_INVALID
+    assert rt.lib.rt_accumulate_static(dev._h, C.byref(cam), C.byref(rt.make_options()), 3, 3, C.c_void_p(buf.address), None) == rt.RT_OK
