@@ -136,6 +136,27 @@ def test_oracle_reproduces_shipped_renders(name, make, mode, mean_tol, rmse_tol)
     assert rmse < rmse_tol, f"blurred rmse {rmse}"
 
 
+@pytest.mark.parametrize("use_libm", [True, False])
+def test_oracle_reproduces_the_references_mirror_cat_render_pixel_by_pixel(use_libm):
+    """The deterministic image among the reference's renders (mirror cat, no anti-aliasing, direct light only;
+    no glass in the scene, so no random number reaches a pixel), compared PER PIXEL at full size and at the
+    PNG's 8-bit resolution: floor(min(v, 255)), the reference's own conversion (src/scene.cu:216-219).  It was
+    drawn with a bounce limit of 7 (MAX_RAY_DEPTH, src/raytrace.cu:12, is 5 in the shipped source): paths
+    between the cat's mirror surfaces that are cut off at 5 bounces leave 168 pixels black that are lit in the
+    image, 6 leave 38, 7 leaves none and 8 lights 70 that are black in the image."""
+    s = variant("mesh_scene", "mirror")
+    desc, cam = s.describe()
+    ref = np.asarray(Image.open(os.path.join(GOLDEN, "reference_renders", "cat_mirror_512x512_32rays.png")).convert("RGB"), np.float32)
+    img, _ = ob.render_image(desc, cam, ob.options(indirect=False, antialiasing=False, bounding_box=True, max_depth=7, use_libm=use_libm))
+    level = np.abs(np.floor(np.minimum(img, 255)) - ref).max(axis=2)
+    assert (level == 0).mean() >= 0.9999    # 262 131 of 262 144 pixels are equal
+    assert (level <= 1).mean() >= 0.99995   # 11 more are one level off (the transfer curve's last bit)
+    assert (level > 1).sum() <= 4           # 2 pixels on silhouettes of the cat's reflection differ
+    if not use_libm:
+        img5, _ = ob.render_image(desc, cam, ob.options(indirect=False, antialiasing=False, bounding_box=True, max_depth=5))
+        assert (np.abs(np.floor(np.minimum(img5, 255)) - ref).max(axis=2) > 1).sum() > 100
+
+
 def test_libm_and_polynomial_oracles_agree():
     """The two math back-ends differ by rounding only: same image up to rare decision flips."""
     s = load("default", 64, 64, 4)
