@@ -245,6 +245,81 @@ __device__ __forceinline__ V3 random_cos(float r1, float r2, V3 N) {
 
 __device__ __forceinline__ V3 reflect(V3 ray, V3 N) { return ray - (2 * dot(ray, N)) * N; }
 
+// The material's response to a hit at P with shading normal N (reference get_color,
+// src/raytrace.cu:338-437): the point and direction the path continues from, whether the lights are
+// evaluated here (`lit`: diffuse hit), whether the path goes on (`alive`) and whether its weight
+// picks up the surface colour (`tinted`).  `ray` is the incoming direction on entry.  N comes back
+// flipped when a glass surface is left from the inside.
+__device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const SceneCache& cache, const Frame& f, const rt_rng_key& rng,
+                                               int depth, int m, V3 P, V3& N, V3& start, V3& ray, V3 weight, V3& colour,
+                                               uint32_t& dim, uint32_t& flags, bool& alive, bool& lit, bool& tinted) {
+    const float4 mc = material_color(sc, cache, (uint32_t)m);
+    const int type = __float_as_int(mc.w);
+    colour = xyz(mc);
+    V3 next_weight = weight;
+    alive = true;
+
+    if (type == RT_DIFFUSE) {
+        if (!f.indirect && depth == 0) flags |= F_EARLY;
+        if (f.antialiasing) flags &= ~F_EARLY;
+        lit = true;
+        start = P + scale_d(0.01, N);
+        if (!f.indirect) {
+            alive = false;
+        } else {
+            next_weight = weight * colour;
+            tinted = true;
+            const float r1 = rt_rng_uniform(rng, dim);
+            const float r2 = rt_rng_uniform(rng, dim + 1);
+            dim += 2;
+            ray = random_cos(r1, r2, N);
+        }
+    } else if (type == RT_MIRROR) {
+        const V3 rr = reflect(ray, N);
+        start = P + scale_d(0.01, N);
+        ray = rr;
+    } else { // RT_GLASS
+        const float2 ior = material_ior(sc, cache, (uint32_t)m);
+        float ro = ior.x, ri = ior.y;
+        float wn = dot(ray, N);
+        // Schlick reflectance (reference src/raytrace.cu:388-394)
+        const float k0 = (ro - ri) * (ro - ri) / ((ro + ri) * (ro + ri));
+        const float om = 1.f - fabsf(wn);
+        const float om2 = om * om;
+        const float R = k0 + (1.f - k0) * om2 * om2 * om;
+        const float r = rt_rng_uniform(rng, dim);
+        dim += 1;
+        if (r < R) {
+            const V3 rr = reflect(ray, N);
+            start = P + scale_d(0.01, N);
+            ray = rr;
+        } else {
+            if (wn > 0) { // leaving the medium: swap indices, flip the normal
+                const float sw = ro; ro = ri; ri = sw;
+                N = -1.f * N;
+                wn = dot(ray, N);
+            }
+            const float eta = ro / ri;
+            const float k = 1.f - eta * eta * (1.f - wn * wn);
+            if (k < 0) { // total internal reflection
+                const V3 rr = reflect(ray, N);
+                start = P + scale_d(0.01, N);
+                ray = rr;
+            } else {
+                const V3 wt_t = eta * (ray - wn * N);
+                const V3 wt_n = (-sqrt_rn(k)) * N;
+                start = P - scale_d(0.01, N);
+                ray = wt_t + wt_n;
+            }
+        }
+    }
+    if (depth + 1 >= f.max_depth) alive = false;
+    // A weight of exactly zero in all three channels (a pure red wall seen from a pure
+    // green one) stays zero, and every later term of the path is weight * direct light
+    // with a finite direct light: the path has nothing more to add.
+    if (f.prune_zero_terms && next_weight.x == 0.f && next_weight.y == 0.f && next_weight.z == 0.f) alive = false;
+}
+
 // One bounce of every live path (reference get_color loop body,
 // src/raytrace.cu:317-442).  `depth` is the bounce index; counter depth+1
 // receives the rays this bounce queues for k_mesh.
@@ -332,74 +407,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                     m = __float_as_int(s0.w);
                     N = normalize((alpha * xyz(s0) + beta * xyz(s1)) + gamma * xyz(s2));
                 }
-                const float4 mc = material_color(sc, cache, (uint32_t)m);
-                const int type = __float_as_int(mc.w);
-                colour = xyz(mc);
                 weight = xyz(th);
-                V3 next_weight = weight;
                 uint32_t dim = __float_as_uint(th.w);
                 const rt_rng_key rng = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
-                alive = true;
-
-                if (type == RT_DIFFUSE) {
-                    if (!f.indirect && depth == 0) flags |= F_EARLY;
-                    if (f.antialiasing) flags &= ~F_EARLY;
-                    lit = true;
-                    start = P + scale_d(0.01, N);
-                    if (!f.indirect) {
-                        alive = false;
-                    } else {
-                        next_weight = weight * colour;
-                        tinted = true;
-                        const float r1 = rt_rng_uniform(rng, dim);
-                        const float r2 = rt_rng_uniform(rng, dim + 1);
-                        dim += 2;
-                        ray = random_cos(r1, r2, N);
-                    }
-                } else if (type == RT_MIRROR) {
-                    const V3 rr = reflect(ray, N);
-                    start = P + scale_d(0.01, N);
-                    ray = rr;
-                } else { // RT_GLASS
-                    const float2 ior = material_ior(sc, cache, (uint32_t)m);
-                    float ro = ior.x, ri = ior.y;
-                    float wn = dot(ray, N);
-                    // Schlick reflectance (reference src/raytrace.cu:388-394)
-                    const float k0 = (ro - ri) * (ro - ri) / ((ro + ri) * (ro + ri));
-                    const float om = 1.f - fabsf(wn);
-                    const float om2 = om * om;
-                    const float R = k0 + (1.f - k0) * om2 * om2 * om;
-                    const float r = rt_rng_uniform(rng, dim);
-                    dim += 1;
-                    if (r < R) {
-                        const V3 rr = reflect(ray, N);
-                        start = P + scale_d(0.01, N);
-                        ray = rr;
-                    } else {
-                        if (wn > 0) { // leaving the medium: swap indices, flip the normal
-                            const float sw = ro; ro = ri; ri = sw;
-                            N = -1.f * N;
-                            wn = dot(ray, N);
-                        }
-                        const float eta = ro / ri;
-                        const float k = 1.f - eta * eta * (1.f - wn * wn);
-                        if (k < 0) { // total internal reflection
-                            const V3 rr = reflect(ray, N);
-                            start = P + scale_d(0.01, N);
-                            ray = rr;
-                        } else {
-                            const V3 wt_t = eta * (ray - wn * N);
-                            const V3 wt_n = (-sqrt_rn(k)) * N;
-                            start = P - scale_d(0.01, N);
-                            ray = wt_t + wt_n;
-                        }
-                    }
-                }
-                if (depth + 1 >= f.max_depth) alive = false;
-                // A weight of exactly zero in all three channels (a pure red wall seen from a pure
-                // green one) stays zero, and every later term of the path is weight * direct light
-                // with a finite direct light: the path has nothing more to add.
-                if (f.prune_zero_terms && next_weight.x == 0.f && next_weight.y == 0.f && next_weight.z == 0.f) alive = false;
+                respond_to_hit(sc, cache, f, rng, depth, m, P, N, start, ray, weight, colour, dim, flags, alive, lit, tinted);
                 next_dim = dim;
             }
         }
@@ -487,6 +498,183 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     const V3 next_weight = tinted ? weight * colour : weight;
     finish_bounce(w, counter, last_want, start, last_sray, last_slot, last_dist, alive, walk, ray, ts, sid,
                   make_float4(next_weight.x, next_weight.y, next_weight.z, __uint_as_float(next_dim)), p | (deferred ? kLivePending : 0u));
+}
+
+// ---- scenes without triangles: the whole sample loop in registers -------
+//
+// Without a mesh no ray ever waits for the triangle stage, so nothing has to go through memory:
+// a lane owns a PIXEL and runs the reference's own loop nest (samples, then bounces;
+// src/raytrace.cu:478-500 and :317-442) with the path in registers, adding each sample's colour
+// to the pixel's running sum in sample order.  No queue, no path state, no batches: one launch
+// renders all samples of a band of rows.  The arithmetic per bounce is k_shade's (respond_to_hit
+// and the same sphere scans), so the sums are the ones k_generate / k_shade / k_accumulate produce.
+//
+// The anti-aliasing draws of kTraceGroup samples are searched back to back, as in k_generate.
+constexpr uint32_t kTraceGroup = 4;
+
+__global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame f, uint32_t n_samples, float4* __restrict__ sum,
+                                                          float4* __restrict__ rad, uint32_t* __restrict__ cast_count) {
+    __shared__ SceneCache cache;
+    __shared__ uint32_t accepted[kTraceGroup][kBlock]; // first dimension of the accepted draw, per sample of the group
+    __shared__ float4 eye_oc[kSphereCache];            // per cached sphere: OC = eye - centre, |OC| * |OC|
+    stage_scene(sc, cache);
+    if (threadIdx.x < min(sc.n_spheres, kSphereCache)) {
+        const V3 oc = mk(f.pos[0], f.pos[1], f.pos[2]) - xyz(cache.sphere[threadIdx.x]);
+        const float ocn = norm(oc);
+        eye_oc[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, ocn * ocn);
+    }
+    __syncthreads();
+    // rad == nullptr: a lane owns a pixel and all n_samples samples, and keeps the running sum.
+    // Otherwise (frames of few pixels, which would not fill the chip that way): a lane owns
+    // kTraceGroup consecutive samples of a pixel and writes each sample's colour and flags to
+    // rad[sample * n_pixels + pixel]; k_accumulate then adds them up in sample order.
+    const bool buffered = rad != nullptr;
+    const uint32_t id = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n_groups = (n_samples + kTraceGroup - 1) / kTraceGroup;
+    const bool real = buffered ? id < f.n_pixels * n_groups : id < f.n_pixels; // lanes past the end do nothing
+    const uint32_t px = real ? (buffered ? id % f.n_pixels : id) : 0;
+    const uint32_t s_first = buffered && real ? (id / f.n_pixels) * kTraceGroup : 0;
+    const uint32_t s_end = buffered ? min(s_first + kTraceGroup, n_samples) : n_samples;
+    const uint32_t pixel = f.pixel_offset + px;
+    const uint32_t ux = pixel % f.width, uy = pixel / f.width;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!buffered && real) acc = sum[pixel];
+    bool done = !real; // the reference's terminate_early: the sample loop of this pixel has ended
+    uint32_t n_casts = 0;
+    const V3 eye = mk(f.pos[0], f.pos[1], f.pos[2]);
+
+    for (uint32_t s0 = s_first; s0 < s_end; s0 += kTraceGroup) {
+        if (__ballot(!done) == 0) break;
+        const uint32_t group = min(kTraceGroup, s_end - s0);
+        if (f.antialiasing) { // the accepted draw of every sample of the group (see k_generate)
+            uint32_t r = 0, dim = 0;
+            rt_rng_key key = rt_rng_make_key(f.seed, pixel, f.sample_begin + s0);
+            while (r < group) {
+                const float r1 = rt_rng_uniform(key, dim);
+                bool accept = false;
+                if (r1 >= 0.77f) {
+                    const float r2 = rt_rng_uniform(key, dim + 1);
+                    const float radius = __builtin_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1));
+                    const float m = fmaxf(fabsf(radius * __builtin_amdgcn_cosf(r2)), fabsf(radius * __builtin_amdgcn_sinf(r2)));
+                    if (m < 0.4999f) {
+                        accept = true;
+                    } else if (!(m > 0.5001f)) {
+                        float dx, dy;
+                        jitter_exact(key, dim, dx, dy);
+                        accept = !(fabsf(dx) > 0.5f || fabsf(dy) > 0.5f);
+                    }
+                }
+                if (accept) {
+                    accepted[r][threadIdx.x] = dim;
+                    r++;
+                    dim = 0;
+                    if (r < group) key = rt_rng_make_key(f.seed, pixel, f.sample_begin + s0 + r);
+                } else {
+                    dim += 2;
+                }
+            }
+        }
+        for (uint32_t r = 0; r < group; r++) {
+            if (__ballot(!done) == 0) break;
+            const rt_rng_key rng = rt_rng_make_key(f.seed, pixel, f.sample_begin + s0 + r);
+            // camera sample (reference src/raytrace.cu:479-494), as in k_generate
+            uint32_t dim = 0;
+            float dx = 0.f, dy = 0.f;
+            if (f.antialiasing) {
+                dim = accepted[r][threadIdx.x];
+                jitter_exact(rng, dim, dx, dy);
+                dim += 2;
+            }
+            const float fpx = (float)ux + 0.5f + dx;
+            const float fpy = (float)uy + 0.5f + dy;
+            const V3 dir = normalize(mk((fpx - f.cx) / f.fx, (fpy - f.cy) / f.fy, 1.f));
+            V3 ray = mk(dot(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
+                        dot(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
+                        dot(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
+            V3 start = eye;
+            int sid = -1;
+            float ts = INFINITY;
+            {
+                const uint32_t cached = min(sc.n_spheres, kSphereCache);
+                for (uint32_t i = 0; i < cached; i++) {
+                    const float4 e = eye_oc[i];
+                    sphere_step(dot(ray, xyz(e)), e.w, cache.sphere[i].w, i, ts, sid);
+                }
+                for (uint32_t i = cached; i < sc.n_spheres; i++) {
+                    const float4 sph = sc.sphere[i];
+                    const V3 oc = start - xyz(sph);
+                    const float ocn = norm(oc);
+                    sphere_step(dot(ray, oc), ocn * ocn, sph.w, i, ts, sid);
+                }
+            }
+            n_casts += (uint32_t)__popcll(__ballot(!done));
+
+            // the bounce loop (reference get_color, src/raytrace.cu:317-442)
+            V3 L = mk(0, 0, 0), weight = mk(1.f, 1.f, 1.f);
+            uint32_t flags = 0;
+            bool open = !done; // the path still bounces
+            for (int depth = 0; depth < f.max_depth; depth++) {
+                if (__ballot(open) == 0) break;
+                bool alive = false, lit = false, tinted = false;
+                V3 P = mk(0, 0, 0), N = mk(0, 0, 1), colour = mk(0, 0, 0);
+                if (open && sid >= 0) {
+                    float min_dist = INFINITY;
+                    if (ts < min_dist) min_dist = ts;
+                    P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : start + min_dist * ray;
+                    const int m = sphere_material(sc, cache, (uint32_t)sid);
+                    N = normalize(P - xyz(sphere_at(sc, cache, (uint32_t)sid)));
+                    respond_to_hit(sc, cache, f, rng, depth, m, P, N, start, ray, weight, colour, dim, flags, alive, lit, tinted);
+                }
+                // shadow rays of a diffuse hit and the bounce ray, as in k_shade
+                ts = INFINITY;
+                sid = -1;
+                bool bounce_probed = false;
+                for (uint32_t l = 0; l < sc.n_lights; l++) {
+                    if (l > 0 && __ballot(lit) == 0) break;
+                    const float4 li = light_at(sc, cache, l);
+                    const V3 lp = xyz(li);
+                    const V3 sp_ = lp - P;
+                    const float d = norm(sp_);
+                    const V3 wi = (1.f / d) * sp_;
+                    const float nwi = fmaxf(dot(N, wi), 0.f);
+                    const V3 sray = normalize(lp - start);
+                    const float dist = norm(lp - start);
+                    float ds = INFINITY;
+                    int shadow_sid = -1;
+                    if (l == 0) {
+                        nearest_sphere_pair(sc, cache, start, lit, sray, ds, shadow_sid, alive, ray, ts, sid);
+                        bounce_probed = true;
+                    } else if (lit) {
+                        ds = nearest_sphere(sc, cache, sray, start, shadow_sid);
+                    }
+                    if (lit) {
+                        const bool blocked = ds < dist;
+                        const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
+                        const V3 direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
+                        L = L + weight * direct;
+                    }
+                }
+                if (!bounce_probed && alive) ts = nearest_sphere(sc, cache, ray, start, sid); // a scene without lights
+                n_casts += (uint32_t)__popcll(__ballot(lit)) * sc.n_lights + (uint32_t)__popcll(__ballot(alive));
+                if (tinted) weight = weight * colour;
+                open = alive;
+            }
+            if (buffered) {
+                if (real) rad[(size_t)(s0 + r) * f.n_pixels + px] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
+            } else if (!done) {
+                acc.x += L.x;
+                acc.y += L.y;
+                acc.z += L.z;
+                acc.w += 1.f;
+                if (!f.indirect && (flags & F_EARLY)) done = true;
+            }
+        }
+    }
+    if (!buffered && real) sum[pixel] = acc;
+    if (f.count_casts && n_casts && __lane_id() == 0) {
+        const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kCastShards;
+        atomicAdd(&cast_count[(size_t)shard * kCountStride], n_casts);
+    }
 }
 
 // Per pixel: add the batch's sample colours to the running sum in sample

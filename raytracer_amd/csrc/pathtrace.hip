@@ -87,6 +87,8 @@ struct rt_scene {
     // batch work buffers, grown on demand
     WorkSet ws{};
     void* work_block = nullptr;
+    float4* sphere_rad = nullptr;        // per-sample colours of a scene without triangles (accumulate_spheres)
+    size_t sphere_rad_paths = 0;
     std::vector<uint32_t> cluster_tris;  // triangles per culling cluster
     // profiling events
     std::vector<hipEvent_t> events;   // pool, reused by every call
@@ -612,6 +614,7 @@ extern "C" int rt_scene_free(rt_scene* s) {
     if (s->frame_end) (void)hipEventDestroy(s->frame_end);
     if (s->frame_sum) (void)hipFree(s->frame_sum);
     if (s->frame_out) (void)hipFree(s->frame_out);
+    if (s->sphere_rad) (void)hipFree(s->sphere_rad);
     delete s;
     return RT_OK;
 }
@@ -757,6 +760,105 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
     return RT_OK;
 }
 
+// rt_accumulate_rows for a scene without triangles: k_trace_spheres runs the sample and bounce
+// loops in registers, so there is no path state and no queue.  A band of many pixels is rendered
+// by one launch, a lane per pixel.  A band of few pixels would not fill the chip that way: there a
+// lane takes four samples of a pixel and the per-sample colours go through `rad` (16 bytes per
+// path, batches of at most 2^24 paths) to k_accumulate, which adds them in sample order -- the
+// same sums, bit for bit.  rad == nullptr selects the first arrangement whatever the size.
+// `cast_count` (kCastShards counters) is only touched when stats are wanted.
+constexpr uint32_t kDirectPixels = 1u << 20; // from this many pixels on, a lane per pixel fills the chip
+
+int accumulate_spheres(rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin, uint32_t sample_end,
+                       uint32_t row_begin, uint32_t row_end, float* d_sum, hipStream_t stream, rt_stats* stats,
+                       float4* rad, uint32_t* cast_count, bool report_progress) {
+    Frame f = make_frame(cam, opt);
+    f.count_casts = stats != nullptr;
+    f.prune_zero_terms = opt->cluster_culling != 0;
+    const uint32_t n_samples = sample_end - sample_begin;
+    const uint64_t total_paths = (uint64_t)n_samples * (row_end - row_begin) * cam->width;
+    if (stats) {
+        if (!s->frame_begin) HIP_TRY(hipEventCreate(&s->frame_begin));
+        if (!s->frame_end) HIP_TRY(hipEventCreate(&s->frame_end));
+        HIP_TRY(hipMemsetAsync(cast_count, 0, (size_t)kCastShards * kCountStride * sizeof(uint32_t), stream));
+        HIP_TRY(hipEventRecord(s->frame_begin, stream));
+    }
+    uint64_t paths = 0;
+    uint32_t launches = 0;
+    auto after_launch = [&](uint64_t n_paths) -> int {
+        HIP_TRY(hipGetLastError());
+        launches++;
+        paths += n_paths;
+        if (report_progress && s->progress) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            s->progress(paths, total_paths, s->progress_user);
+        }
+        return RT_OK;
+    };
+    int rc;
+    if (!rad) {
+        f.n_pixels = (row_end - row_begin) * cam->width;
+        f.pixel_offset = row_begin * cam->width;
+        // one launch for all samples; with a progress callback, launches of about 2^24 paths
+        uint32_t per_launch = n_samples;
+        if (report_progress && s->progress) per_launch = std::max(1u, std::min(n_samples, kMaxPathsPerBatch / std::max(f.n_pixels, 1u)));
+        for (uint32_t first = 0; first < n_samples; first += per_launch) {
+            const uint32_t n = std::min(per_launch, n_samples - first);
+            f.sample_begin = sample_begin + first;
+            hipLaunchKernelGGL(k_trace_spheres, dim3((f.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
+                               reinterpret_cast<float4*>(d_sum), (float4*)nullptr, cast_count);
+            if ((rc = after_launch((uint64_t)n * f.n_pixels)) != RT_OK) return rc;
+        }
+    } else {
+        const BatchShape shape = batch_shape(cam->width, row_end - row_begin, n_samples, kMaxPathsPerBatch);
+        Work w{};
+        w.rad = rad;
+        for (uint32_t chunk_row = row_begin; chunk_row < row_end; chunk_row += shape.rows_per_chunk)
+        for (uint32_t first = 0; first < n_samples; first += shape.per_batch) {
+            f.n_pixels = std::min(shape.rows_per_chunk, row_end - chunk_row) * cam->width;
+            f.pixel_offset = chunk_row * cam->width;
+            const uint32_t n = std::min(shape.per_batch, n_samples - first);
+            f.sample_begin = sample_begin + first;
+            f.n_paths = n * f.n_pixels;
+            const uint32_t lanes = f.n_pixels * ((n + kTraceGroup - 1) / kTraceGroup);
+            hipLaunchKernelGGL(k_trace_spheres, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
+                               reinterpret_cast<float4*>(d_sum), rad, cast_count);
+            hipLaunchKernelGGL(k_accumulate, dim3((f.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, w, f,
+                               reinterpret_cast<float4*>(d_sum));
+            if ((rc = after_launch(f.n_paths)) != RT_OK) return rc;
+        }
+    }
+    if (stats) {
+        HIP_TRY(hipEventRecord(s->frame_end, stream));
+        std::vector<uint32_t> counts((size_t)kCastShards * kCountStride);
+        HIP_TRY(hipMemcpyAsync(counts.data(), cast_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventSynchronize(s->frame_end));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->frame_begin, s->frame_end));
+        stats->gpu_ms = ms;
+        stats->batches = launches;
+        stats->paths = paths;
+        for (size_t i = 0; i < counts.size(); i += kCountStride) stats->sphere_casts += counts[i];
+    }
+    return RT_OK;
+}
+
+// The per-sample colour buffer of the second arrangement, for batches of up to n_paths paths.
+int ensure_sphere_rad(rt_scene* s, size_t n_paths) {
+    if (s->sphere_rad_paths >= n_paths) return RT_OK;
+    if (s->sphere_rad) (void)hipFree(s->sphere_rad);
+    s->sphere_rad = nullptr;
+    s->sphere_rad_paths = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&s->sphere_rad), n_paths * sizeof(float4)) != hipSuccess) {
+        (void)hipGetLastError();
+        rt_set_error("out of device memory: %zu bytes of per-sample colours", n_paths * sizeof(float4));
+        return RT_ERR_NOMEM;
+    }
+    s->sphere_rad_paths = n_paths;
+    return RT_OK;
+}
+
 int check_accumulate(const rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin, uint32_t sample_end,
                      uint32_t row_begin, uint32_t row_end, const float* d_sum) {
     int rc = check_frame(s, cam, opt);
@@ -775,11 +877,23 @@ extern "C" int rt_accumulate_rows(rt_scene* s, const rt_camera* cam, const rt_op
     if (rc != RT_OK) return rc;
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (row_end == row_begin || sample_end == sample_begin) return RT_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (s->d.n_triangles == 0) { // no mesh: no path state and no queue
+        if (stats && (rc = ensure_work(s, 1, 1)) != RT_OK) return rc; // the statistics counters
+        const uint32_t band_pixels = (row_end - row_begin) * cam->width;
+        // without indirect light and anti-aliasing most pixels stop after one sample, which only the lane-per-pixel loop exploits
+        const bool direct = band_pixels >= kDirectPixels || (!opt->indirect && !opt->antialiasing) || sample_end - sample_begin == 1;
+        if (!direct) {
+            const BatchShape shape = batch_shape(cam->width, row_end - row_begin, sample_end - sample_begin, kMaxPathsPerBatch);
+            if ((rc = ensure_sphere_rad(s, (size_t)shape.per_batch * shape.rows_per_chunk * cam->width)) != RT_OK) return rc;
+        }
+        return accumulate_spheres(s, cam, opt, sample_begin, sample_end, row_begin, row_end, d_sum, stream, stats,
+                                  direct ? nullptr : s->sphere_rad, stats ? s->ws.w.cast_count : nullptr, true);
+    }
     // A batch is at most 2^24 paths.
     const BatchShape shape = batch_shape(cam->width, row_end - row_begin, sample_end - sample_begin, kMaxPathsPerBatch);
     if ((rc = ensure_work(s, shape.per_batch * shape.rows_per_chunk * cam->width, (uint32_t)opt->max_depth + 1u)) != RT_OK) return rc;
-    return accumulate_batches(s, s->ws, shape, cam, opt, sample_begin, sample_end, row_begin, row_end, d_sum,
-                              static_cast<hipStream_t>(stream_), stats, true);
+    return accumulate_batches(s, s->ws, shape, cam, opt, sample_begin, sample_end, row_begin, row_end, d_sum, stream, stats, true);
 }
 
 extern "C" int rt_accumulate_static(rt_scene* s, const rt_camera* cam, const rt_options* opt, uint32_t sample_begin,
@@ -787,6 +901,9 @@ extern "C" int rt_accumulate_static(rt_scene* s, const rt_camera* cam, const rt_
     int rc = check_accumulate(s, cam, opt, sample_begin, sample_end, 0, cam ? cam->height : 0, d_sum);
     if (rc != RT_OK) return rc;
     if (cam->height == 0 || sample_end == sample_begin) return RT_OK;
+    if (s->d.n_triangles == 0) // no mesh: the paths live in registers and need no work area at all
+        return accumulate_spheres(s, cam, opt, sample_begin, sample_end, 0, cam->height, d_sum, static_cast<hipStream_t>(stream_),
+                                  nullptr, nullptr, nullptr, false);
     unsigned char* area = nullptr;
     if ((rc = static_work_area(&area)) != RT_OK) return rc;
     // The largest batch whose work buffers fit the area (at most half of it for cluster lists): the
