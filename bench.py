@@ -46,7 +46,11 @@ def cpu_baseline(desc, cam, opt, n_pixels_sample=65536):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    # every CPU this process may run on (the GPU box grants a share of the machine per GPU and
+    # exports it as OMP_NUM_THREADS; os.cpu_count() there is the whole machine)
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or allowed
+    threads = max(1, min(threads, allowed))
     rng = np.random.default_rng(1234)
     pixels = rng.choice(cam.width * cam.height, size=n_pixels_sample, replace=False).astype(np.uint32)
     oopt = ob.from_rt_options(opt)
@@ -61,6 +65,8 @@ def cpu_baseline(desc, cam, opt, n_pixels_sample=65536):
         "value": counters["paths"] / dt / 1e6,
         "unit": "Mpaths/s",
         "cores": threads,
+        "host_cpus": os.cpu_count(),
+        "cpus_allowed": allowed,
         "kind": "port",
         "sample": f"{n_pixels_sample} random pixels x {cam.num_rays} spp of the same frame "
                   f"({counters['paths']} paths, {dt:.1f} s, {counters['triangle_tests'] / counters['paths']:.0f} "
@@ -90,6 +96,7 @@ class Meter:
         self.frames += 1
 
     def roofline(self, kernel, step_ms, traffic):
+        """The triangle kernel: 47 flop per ray-triangle test it executed."""
         achieved = self.tests * FLOP_PER_TRIANGLE_TEST / (self.mesh_ms * 1e-3) / 1e12 if self.mesh_ms > 0 else 0.0
         return {
             "bound": "valu",
@@ -107,6 +114,7 @@ class Meter:
             "triangle_tests_per_step": self.tests / max(self.frames, 1),
             "kernel_share_of_step": self.mesh_ms / max(self.frames, 1) / step_ms if step_ms else None,
             "binning_ms_per_step": self.bin_ms / max(self.frames, 1),
+            "sampled_steps": self.frames,
         }
 
     def shade_roofline(self, step_ms, n_spheres, n_boxes, generate_casts_per_frame, traffic):
@@ -118,6 +126,7 @@ class Meter:
         casts = self.casts - generate_casts_per_frame * self.frames  # camera rays are cast by k_generate
         flop = casts * (FLOP_PER_SPHERE_TEST * n_spheres + FLOP_PER_BOX_TEST * n_boxes)
         achieved = flop / (self.shade_ms * 1e-3) / 1e12
+        hbm = traffic / (self.shade_ms / self.shade_launches * 1e-3) / 1e9 if traffic else None
         return {
             "bound": "valu",
             "kernel": "k_shade",
@@ -126,19 +135,32 @@ class Meter:
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
             "traffic": traffic,
-            "hbm_gbps": traffic / (self.shade_ms / self.shade_launches * 1e-3) / 1e9 if traffic else None,
+            "hbm_gbps": hbm,
             "hbm_peak_gbps": 8000.0,
+            "hbm_frac": hbm / 8000.0 if hbm else None,
             "avg_launch_ms": self.shade_ms / self.shade_launches,
             "launches_per_step": self.shade_launches / max(self.frames, 1),
             "casts_per_step": casts / max(self.frames, 1),
             "kernel_share_of_step": self.shade_ms / max(self.frames, 1) / step_ms if step_ms else None,
+            "sampled_steps": self.frames,
+            "note": "dominant kernel of the step; instruction-issue bound (VALU busy in profiles/), its own arithmetic "
+                    "(hit selection, materials, IEEE divisions and square roots, the generator) is not counted as algorithmic work",
         }
+
+    def frame_roofline(self, step_ms, n_spheres, n_boxes):
+        """The whole step on the algorithmic work it executed: triangle tests, sphere tests and box tests of every ray."""
+        if not self.frames or not step_ms:
+            return None
+        flop = (self.tests * FLOP_PER_TRIANGLE_TEST + self.casts * (FLOP_PER_SPHERE_TEST * n_spheres + FLOP_PER_BOX_TEST * n_boxes)) / self.frames
+        achieved = flop / (step_ms * 1e-3) / 1e12
+        return {"bound": "valu", "kernel": "whole step", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None, "gflop_per_step": flop / 1e9}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="mesh_scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,10 +216,11 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             # Steps just enqueue: consecutive frames overlap on the device (a stream per frame in flight), and with
-            # N > 1 so do the all-reduce of one frame and the kernels of the next.  Every 32nd step
-            # is a sampling step: the device is drained first, so that the frame runs alone and the
-            # HIP events around its triangle kernels time them undisturbed; its counters are read back.
-            sampling = i % 32 == 0
+            # N > 1 so do the all-reduce of one frame and the kernels of the next.  Three steps of the
+            # region (at its start, one third and two thirds) are sampling steps: the device is drained first,
+            # so that the frame runs alone and the HIP events around its kernels time them undisturbed; its
+            # counters are read back.
+            sampling = i in (0, steps // 3, (2 * steps) // 3)
             if sampling:
                 torch.cuda.synchronize()
             renderer.want_stats = sampling
@@ -217,6 +240,18 @@ def main():
     fence()
 
     elapsed, meter, opt = run(True, args.steps, args.warmup)
+    # the time of ONE frame on its own (nothing else in flight), beside the throughput figure above
+    single_opt = rt.make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1)
+    single = FrameRenderer(dev, cam, single_opt)
+    single.render()
+    fence()
+    single_frames = max(3, min(args.steps, 20))
+    t0 = time.perf_counter()
+    for _ in range(single_frames):
+        single.render()
+        torch.cuda.synchronize()
+    single_ms = (time.perf_counter() - t0) / single_frames * 1e3
+    fence()
     exhaustive = None
     if not args.no_exhaustive:
         ex_steps = max(1, min(args.steps, 5))
@@ -239,12 +274,14 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "s_per_frame": ms_per_step / 1e3,
+            "s_per_frame": ms_per_step / 1e3,  # inverse throughput with frames in flight
+            "s_per_frame_single": single_ms / 1e3,  # one frame rendered alone, submit to finished (frames_in_flight = 1)
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": value / BASELINE_MPATHS,
             "dtype": "f32",
-            "data": "synthetic scene file shipped with the repo (mesh_scene.json + cat.obj), fixed seed",
+            "data": "the reference's own scene (assets/scenes/mesh_scene.json and the cat.obj mesh it names, byte-identical copies), "
+                    "fixed seed; nothing synthetic",
             "config": {
                 "workload": f"{args.scene}.json {cam.width}x{cam.height} {spp}spp depth5 indirect+AA+bbox",
                 "triangles": int(desc.n_triangles),
@@ -252,17 +289,20 @@ def main():
                 "parallelism": f"spp-split x{world} + RCCL all-reduce of linear radiance" if world > 1 else "single GPU",
                 "frames_in_flight": max(args.frames_in_flight, 1),
             },
-            # dominant kernel of the timed region: k_mesh_clusters.  Algorithmic
-            # flops of rank 0's launches (47 per ray-triangle test executed)
-            # over their summed duration, from HIP events on the launch stream.
-            "roofline": meter.roofline("k_mesh_clusters", ms_per_step, traffic.get("k_mesh_clusters_hbm_bytes_per_launch")),
         }
         from raytracer_amd.distributed import sample_range
         begin, end = sample_range(0, world, spp)  # rank 0's share (the statistics are rank 0's)
         own_samples = end - begin
-        # the other large kernel of the default mode (about half of the frame since the culling)
-        line["roofline_k_shade"] = meter.shade_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes), n_pixels * own_samples,
-                                                          traffic.get("k_shade_hbm_bytes_per_launch"))
+        # `roofline` names the kernel with the largest share of the step (k_shade in the default mode).  Durations are
+        # HIP events on the launch stream around rank 0's launches on the sampling steps; algorithmic work per test as above.
+        shade = meter.shade_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes), n_pixels * own_samples,
+                                     traffic.get("k_shade_hbm_bytes_per_launch"))
+        mesh = meter.roofline("k_mesh_clusters", ms_per_step, traffic.get("k_mesh_clusters_hbm_bytes_per_launch"))
+        if shade is not None and shade["kernel_share_of_step"] >= (mesh["kernel_share_of_step"] or 0):
+            line["roofline"], line["roofline_k_mesh_clusters"] = shade, mesh
+        else:
+            line["roofline"], line["roofline_k_shade"] = mesh, shade
+        line["roofline_whole_step"] = meter.frame_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes))
         if exhaustive is not None:
             ex_elapsed, ex_meter, ex_steps = exhaustive
             line["exhaustive_scan"] = {
