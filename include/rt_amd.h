@@ -154,6 +154,37 @@ int rt_accumulate_rows(rt_scene* scene, const rt_camera* cam, const rt_options* 
                        uint32_t sample_begin, uint32_t sample_end, uint32_t row_begin,
                        uint32_t row_end, float* d_sum, void* stream, rt_stats* stats);
 
+/* d_dst[i] += d_src[i] for n_floats floats of DEVICE memory on the current
+ * device (16-byte aligned buffers): adds the sums another device produced,
+ * after they were copied here, before rt_resolve. */
+int rt_add_sums(float* d_dst, const float* d_src, uint32_t n_floats, void* stream);
+
+/* The share of one frame that device `rank` of `world` renders:
+ * out = {sample_begin, sample_end, row_begin, row_end}.  Samples are split
+ * first (every device sees all pixels: perfectly balanced); only with more
+ * devices than samples per pixel is the image also cut into bands of rows
+ * (sample groups x bands, groups = the largest divisor of world <= spp). */
+void rt_frame_partition(uint32_t rank, uint32_t world, uint32_t spp, uint32_t height, uint32_t out[4]);
+
+/* One frame over several GPUs of one node from ONE process (the reference
+ * renders on one GPU; this splits its sample loop, src/raytrace.cu:478-500).
+ * rt_device_group_create uploads the scene to every listed device (HIP device
+ * indices; the first one collects the result).  rt_device_group_render has
+ * every device accumulate its rt_frame_partition share (one host thread per
+ * device), sums the linear buffers on the first device -- ncclReduce over
+ * RCCL when librccl can be loaded at run time, otherwise (or with
+ * RT_AMD_EXCHANGE=peer in the environment, or when a device is listed twice)
+ * peer copies followed by additions in device order -- resolves there and
+ * copies the image to out_rgb (host, 3 * width * height floats).  stats, if
+ * not NULL, are the first device's.  The image is the one rt_render draws up
+ * to the order of the fp32 additions across devices. */
+typedef struct rt_device_group rt_device_group;
+int rt_device_group_create(const rt_scene_desc* desc, const int32_t* devices, uint32_t n_devices,
+                           rt_device_group** out_group);
+int rt_device_group_render(rt_device_group* group, const rt_camera* cam, const rt_options* opt,
+                           float* out_rgb, rt_stats* stats);
+int rt_device_group_free(rt_device_group* group);
+
 /* rt_accumulate for callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It
  * has no counterpart in the reference.  The work buffers rt_accumulate takes
@@ -210,6 +241,10 @@ int rt_host_scene_add_object(rt_host_scene* s, const char* obj_path, const float
                              const float color[3], int32_t material_type, float ro, float ri);
 int rt_host_scene_add_light(rt_host_scene* s, const float pos[3], float intensity);
 int rt_host_scene_set_options(rt_host_scene* s, const rt_options* opt);
+/* Scene::settings.devices: render() and render_frames() split every frame over
+ * HIP devices 0 .. n_devices-1 through an rt_device_group (1 = the current
+ * device only, the default). */
+int rt_host_scene_set_devices(rt_host_scene* s, uint32_t n_devices);
 /* Scene::render: renders on the current device, clamps to 8 bits like the
  * reference (src/scene.cu:214-220) and writes an RGB PNG.  png_path may be
  * NULL to skip the file. */

@@ -127,6 +127,11 @@ def _load() -> C.CDLL:
                                C.POINTER(Stats)],
         "rt_accumulate_static": [vp, C.POINTER(Camera), C.POINTER(Options), C.c_uint32, C.c_uint32, vp, vp],
         "rt_resolve": [vp, C.c_uint32, vp, vp],
+        "rt_add_sums": [vp, vp, C.c_uint32, vp],
+        "rt_device_group_create": [C.POINTER(SceneDesc), _i32p, C.c_uint32, C.POINTER(vp)],
+        "rt_device_group_render": [vp, C.POINTER(Camera), C.POINTER(Options), _f32p, C.POINTER(Stats)],
+        "rt_device_group_free": [vp],
+        "rt_host_scene_set_devices": [vp, C.c_uint32],
         "rt_cast": [vp, C.POINTER(Options), C.c_uint32, _f32p, _f32p, _f32p, _i32p, _i32p, _f32p],
         "rt_visible": [vp, C.POINTER(Options), C.c_uint32, _f32p, _f32p, _i32p],
         "rt_host_scene_create": [C.POINTER(vp)],
@@ -152,6 +157,8 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.rt_frame_partition.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 4)]
+    lib.rt_frame_partition.restype = None
     lib.rt_last_error.argtypes = []
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_host_scene_image.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -169,7 +176,8 @@ EXPORTS = [
     "rt_host_scene_set_num_rays", "rt_host_scene_add_sphere", "rt_host_scene_add_object", "rt_host_scene_add_light",
     "rt_host_scene_set_options", "rt_host_scene_render", "rt_host_scene_describe", "rt_host_scene_image",
     "rt_write_png", "rt_write_pfm", "rt_set_progress", "rt_host_scene_render_frames", "rt_accumulate_rows",
-    "rt_accumulate_static",
+    "rt_accumulate_static", "rt_add_sums", "rt_frame_partition", "rt_device_group_create", "rt_device_group_render",
+    "rt_device_group_free", "rt_host_scene_set_devices",
 ]
 
 
@@ -313,6 +321,43 @@ class DeviceScene:
         return vis
 
 
+class DeviceGroup:
+    """A scene resident on several HIP devices of this node, rendered from this one process (rt_device_group)."""
+
+    def __init__(self, desc: SceneDesc, devices):
+        self._h = C.c_void_p()
+        arr = np.ascontiguousarray(devices, dtype=np.int32)
+        _check(lib.rt_device_group_create(C.byref(desc), _iptr(arr), len(arr), C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib.rt_device_group_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cam: Camera, opt: Options) -> Tuple[np.ndarray, Stats]:
+        out = np.empty((cam.height, cam.width, 3), dtype=np.float32)
+        st = Stats()
+        _check(lib.rt_device_group_render(self._h, C.byref(cam), C.byref(opt), _fptr(out), C.byref(st)))
+        return out, st
+
+
+def frame_partition(rank: int, world: int, spp: int, height: int) -> Tuple[int, int, int, int]:
+    """rt_frame_partition: (sample_begin, sample_end, row_begin, row_end) of `rank`'s share of a frame."""
+    out = (C.c_uint32 * 4)()
+    lib.rt_frame_partition(rank, world, spp, height, C.byref(out))
+    return tuple(int(v) for v in out)
+
+
+def add_sums(d_dst_ptr: int, d_src_ptr: int, n_floats: int, stream: int = 0) -> None:
+    _check(lib.rt_add_sums(C.c_void_p(d_dst_ptr), C.c_void_p(d_src_ptr), n_floats, C.c_void_p(stream)))
+
+
 def resolve(d_sum_ptr: int, n_pixels: int, d_out_ptr: int, stream: int = 0) -> None:
     _check(lib.rt_resolve(C.c_void_p(d_sum_ptr), n_pixels, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
@@ -351,6 +396,10 @@ class Scene:
 
     def transform_camera(self, x: float, y: float, z: float) -> None:
         _check(lib.rt_host_scene_transform_camera(self._h, x, y, z))
+
+    def set_devices(self, n: int) -> None:
+        """Scene::settings.devices: render() splits every frame over HIP devices 0 .. n-1."""
+        _check(lib.rt_host_scene_set_devices(self._h, n))
 
     def set_num_rays(self, n: int) -> None:
         _check(lib.rt_host_scene_set_num_rays(self._h, n))

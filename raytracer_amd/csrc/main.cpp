@@ -16,9 +16,10 @@ namespace {
 
 const char* kUsage =
     "usage: render [scene.json] [--direct] [--no-aa] [--no-bbox] [--exhaustive] [--depth N] [--seed N]\n"
-    "              [-o image.png|image.pfm]\n"
+    "              [-o image.png|image.pfm] [--devices N]\n"
     "              [--frames N --rotate RX RY RZ --move DX DY DZ --first K --stride S --writers T]\n"
-    "  with --frames, -o is a pattern such as frames/frame_%04d.png\n";
+    "  with --frames, -o is a pattern such as frames/frame_%04d.png\n"
+    "  --devices N splits every frame over HIP devices 0..N-1 of this node\n";
 
 bool take3(int argc, char** argv, int& i, Vec3f& out) {
     if (i + 3 >= argc) return false;
@@ -45,6 +46,7 @@ int main(int argc, char** argv) {
         else if (a == "--depth" && i + 1 < argc) s.settings.max_ray_depth = std::atoi(argv[++i]);
         else if (a == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
         else if (a == "-o" && i + 1 < argc) out = argv[++i];
+        else if (a == "--devices" && i + 1 < argc) s.settings.devices = static_cast<unsigned>(std::strtoul(argv[++i], nullptr, 10));
         else if (a == "--frames" && i + 1 < argc) frames = static_cast<unsigned>(std::strtoul(argv[++i], nullptr, 10));
         else if (a == "--first" && i + 1 < argc) first = static_cast<unsigned>(std::strtoul(argv[++i], nullptr, 10));
         else if (a == "--stride" && i + 1 < argc) stride = static_cast<unsigned>(std::strtoul(argv[++i], nullptr, 10));

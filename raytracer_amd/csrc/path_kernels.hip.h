@@ -719,6 +719,19 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ s
     out[3 * pixel + 2] = rt_gamma_encode(inv * s.z);
 }
 
+// dst += src, element by element (the sums of another device arriving on this one)
+__global__ __launch_bounds__(kBlock) void k_add_sums(float4* __restrict__ dst, const float4* __restrict__ src, uint32_t n_vec4,
+                                                     float* __restrict__ dst_tail, const float* __restrict__ src_tail, uint32_t n_tail) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_vec4) {
+        float4 a = dst[i];
+        const float4 b = src[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[i] = a;
+    }
+    if (i < n_tail) dst_tail[i] += src_tail[i];
+}
+
 // ------------------------------------------- known-answer test kernels
 
 // rays -> state + queue, through the same launch_ray the renderer uses

@@ -938,6 +938,17 @@ extern "C" int rt_resolve(const float* d_sum, uint32_t n_pixels, float* d_out_rg
     return RT_OK;
 }
 
+extern "C" int rt_add_sums(float* d_dst, const float* d_src, uint32_t n_floats, void* stream_) {
+    if (!d_dst || !d_src) { rt_set_error("rt_add_sums: null buffer"); return RT_ERR_INVALID; }
+    if (n_floats == 0) return RT_OK;
+    const uint32_t n_vec4 = n_floats / 4, n_tail = n_floats % 4;
+    hipLaunchKernelGGL(k_add_sums, dim3((std::max(n_vec4, n_tail) + kBlock - 1) / kBlock), dim3(kBlock), 0, static_cast<hipStream_t>(stream_),
+                       reinterpret_cast<float4*>(d_dst), reinterpret_cast<const float4*>(d_src), n_vec4, d_dst + 4 * (size_t)n_vec4,
+                       d_src + 4 * (size_t)n_vec4, n_tail);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* opt, float* out_rgb, rt_stats* stats) {
     int rc = check_frame(s, cam, opt);
     if (rc != RT_OK) return rc;

@@ -187,7 +187,10 @@ Scene::~Scene() {
 
 void Scene::release_device_scene() {
     if (device_scene_) rt_scene_free(device_scene_);
+    if (device_group_) rt_device_group_free(device_group_);
     device_scene_ = nullptr;
+    device_group_ = nullptr;
+    group_devices_ = 0;
     device_scene_stale_ = true;
 }
 
@@ -196,7 +199,13 @@ void Scene::load_scene(std::string filepath) {
     if (!ifs.is_open()) throw std::invalid_argument("File not found");
     std::stringstream buffer;
     buffer << ifs.rdbuf();
-    const rt::json::Value jf = rt::json::parse(buffer.str());
+    rt::json::Value parsed;
+    try {
+        parsed = rt::json::parse(buffer.str());
+    } catch (const std::exception& e) {
+        throw SceneError(RT_ERR_PARSE, e.what());
+    }
+    const rt::json::Value& jf = parsed;
 
     sphere_pos_.clear(); sphere_radius_.clear(); sphere_material_.clear();
     material_type_.clear(); material_color_.clear(); material_ro_.clear(); material_ri_.clear();
@@ -312,7 +321,8 @@ void Scene::add_object(std::string obj_path, CU_Vector3f translation, CU_Vector3
     try {
         mesh = rt::obj::load(locate_mesh(obj_path, scene_dir_));
     } catch (const std::exception& e) {
-        throw std::runtime_error(std::string("TinyObjReader: ") + e.what());
+        const std::string what = e.what();
+        throw SceneError(what.find("Cannot open") != std::string::npos ? RT_ERR_IO : RT_ERR_PARSE, "TinyObjReader: " + what);
     }
 
     const int material_index = add_material(material);
@@ -497,7 +507,7 @@ void write_image(const std::string& path, uint32_t width, uint32_t height, const
         std::vector<uint8_t> rgb = quantize(image, size_t(3) * width * height);
         rc = rt_write_png(path.c_str(), width, height, rgb.data());
     }
-    if (rc != RT_OK) throw std::runtime_error(rt_last_error());
+    if (rc != RT_OK) throw SceneError(rc, rt_last_error());
 }
 
 // Host threads that encode finished frames while the device renders the next.
@@ -573,11 +583,11 @@ std::string frame_path(const std::string& pattern, unsigned frame) {
         while (j < pattern.size() && (pattern[j] == '0' || pattern[j] == '-')) j++;
         while (j < pattern.size() && pattern[j] >= '0' && pattern[j] <= '9') j++;
         if (j >= pattern.size() || (pattern[j] != 'd' && pattern[j] != 'u' && pattern[j] != 'i'))
-            throw std::runtime_error("frame pattern: only %d, %u, %i (with width) are accepted");
+            throw SceneError(RT_ERR_INVALID, "frame pattern: only %d, %u, %i (with width) are accepted");
         conversions++;
         i = j;
     }
-    if (conversions != 1) throw std::runtime_error("frame pattern needs exactly one integer conversion, e.g. frame_%04d.png");
+    if (conversions != 1) throw SceneError(RT_ERR_INVALID, "frame pattern needs exactly one integer conversion, e.g. frame_%04d.png");
     std::vector<char> buf(pattern.size() + 32);
     std::snprintf(buf.data(), buf.size(), pattern.c_str(), frame);
     return std::string(buf.data());
@@ -609,13 +619,29 @@ struct ProgressBar {
 } // namespace
 
 void Scene::sync_device_scene() {
-    if (device_scene_stale_ || !device_scene_) {
+    const unsigned devices = settings.devices > 1 ? settings.devices : 1;
+    const bool have = devices > 1 ? (device_group_ && group_devices_ == devices) : device_scene_ != nullptr;
+    if (device_scene_stale_ || !have) {
         rt_scene_desc desc;
         describe(&desc, nullptr);
         release_device_scene();
-        if (rt_scene_upload(&desc, &device_scene_) != RT_OK) throw std::runtime_error(rt_last_error());
+        int rc;
+        if (devices > 1) {
+            std::vector<int32_t> list(devices);
+            for (unsigned i = 0; i < devices; i++) list[i] = static_cast<int32_t>(i);
+            rc = rt_device_group_create(&desc, list.data(), devices, &device_group_);
+            group_devices_ = devices;
+        } else {
+            rc = rt_scene_upload(&desc, &device_scene_);
+        }
+        if (rc != RT_OK) throw SceneError(rc, rt_last_error());
         device_scene_stale_ = false;
     }
+}
+
+int Scene::render_frame(const rt_camera& cam, const rt_options& opt) {
+    if (device_group_) return rt_device_group_render(device_group_, &cam, &opt, image_.data(), &stats_);
+    return rt_render(device_scene_, &cam, &opt, image_.data(), &stats_);
 }
 
 void Scene::render(std::string imagepath, size_t seed) {
@@ -626,11 +652,11 @@ void Scene::render(std::string imagepath, size_t seed) {
     image_.assign(size_t(3) * cam.width * cam.height, 0.f);
 
     ProgressBar bar;
-    if (verbose) rt_set_progress(device_scene_, &ProgressBar::report, &bar);
+    if (verbose && device_scene_) rt_set_progress(device_scene_, &ProgressBar::report, &bar);
     auto t0 = std::chrono::steady_clock::now();
-    const int rc = rt_render(device_scene_, &cam, &opt, image_.data(), &stats_);
-    rt_set_progress(device_scene_, nullptr, nullptr);
-    if (rc != RT_OK) throw std::runtime_error(rt_last_error());
+    const int rc = render_frame(cam, opt);
+    if (device_scene_) rt_set_progress(device_scene_, nullptr, nullptr);
+    if (rc != RT_OK) throw SceneError(rc, rt_last_error());
     double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (verbose) std::printf("Finished raytracing in %.3f seconds.\n", seconds);
 
@@ -639,7 +665,7 @@ void Scene::render(std::string imagepath, size_t seed) {
 
 double Scene::render_frames(std::string pattern, size_t first_seed, unsigned n_frames, CU_Vector3f rotate_step,
                             CU_Vector3f move_step, unsigned first, unsigned stride, unsigned writers) {
-    if (stride == 0) throw std::runtime_error("render_frames: stride must be at least 1");
+    if (stride == 0) throw SceneError(RT_ERR_INVALID, "render_frames: stride must be at least 1");
     if (!pattern.empty()) (void)frame_path(pattern, 0); // reject a bad pattern before any work
     sync_device_scene();
     auto t0 = std::chrono::steady_clock::now();
@@ -655,11 +681,12 @@ double Scene::render_frames(std::string pattern, size_t first_seed, unsigned n_f
             describe(nullptr, &cam);
             rt_options opt = options_from(settings, first_seed + i);
             image_.assign(size_t(3) * cam.width * cam.height, 0.f);
-            if (rt_render(device_scene_, &cam, &opt, image_.data(), &stats_) != RT_OK) throw std::runtime_error(rt_last_error());
+            const int rc = render_frame(cam, opt);
+            if (rc != RT_OK) throw SceneError(rc, rt_last_error());
             if (!pattern.empty()) pool.submit(frame_path(pattern, i), cam.width, cam.height, image_);
         }
         const std::string failure = pool.finish();
-        if (!failure.empty()) throw std::runtime_error(failure);
+        if (!failure.empty()) throw SceneError(RT_ERR_IO, failure);
     }
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (verbose) std::printf("Rendered %u frames in %.3f seconds.\n", n_frames > first ? (n_frames - first + stride - 1) / stride : 0, seconds);
@@ -821,7 +848,10 @@ int guarded(const char* what, F&& body) {
     try {
         body();
         return RT_OK;
-    } catch (const std::invalid_argument& e) {
+    } catch (const SceneError& e) { // carries its class: a device call's own status, a parse or file error
+        rt_set_error("%s: %s", what, e.what());
+        return e.code;
+    } catch (const std::invalid_argument& e) { // the reference's "File not found"
         rt_set_error("%s: %s", what, e.what());
         return RT_ERR_IO;
     } catch (const std::bad_alloc&) {
@@ -829,10 +859,6 @@ int guarded(const char* what, F&& body) {
         return RT_ERR_NOMEM;
     } catch (const std::exception& e) {
         rt_set_error("%s: %s", what, e.what());
-        const std::string msg = e.what();
-        if (msg.find("json:") != std::string::npos) return RT_ERR_PARSE;
-        if (msg.find("TinyObjReader") != std::string::npos) return RT_ERR_IO;
-        if (msg.find("hip") != std::string::npos || msg.find("HIP") != std::string::npos) return RT_ERR_DEVICE;
         return RT_ERR_INVALID;
     }
 }
@@ -922,12 +948,15 @@ int rt_host_scene_set_options(rt_host_scene* s, const rt_options* opt) {
     return RT_OK;
 }
 
+int rt_host_scene_set_devices(rt_host_scene* s, uint32_t n_devices) {
+    if (!s || n_devices == 0 || n_devices > 64) { rt_set_error("rt_host_scene_set_devices: bad argument"); return RT_ERR_INVALID; }
+    s->scene.settings.devices = n_devices;
+    return RT_OK;
+}
+
 int rt_host_scene_render(rt_host_scene* s, const char* png_path, size_t seed) {
     if (!s) { rt_set_error("rt_host_scene_render: null scene"); return RT_ERR_INVALID; }
-    int rc = guarded("rt_host_scene_render", [&] { s->scene.render(png_path ? png_path : "", seed); });
-    // failures inside render come from the device half, which already set
-    // the message; classify them as device errors
-    return rc == RT_ERR_INVALID ? RT_ERR_DEVICE : rc;
+    return guarded("rt_host_scene_render", [&] { s->scene.render(png_path ? png_path : "", seed); });
 }
 
 int rt_host_scene_render_frames(rt_host_scene* s, const char* pattern, size_t first_seed, uint32_t n_frames,

@@ -10,6 +10,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,13 @@ struct Mat4 {
 };
 
 enum material_type { DIFFUSE = 0, MIRROR, GLASS };
+
+// What class Scene throws besides the reference's std::invalid_argument("File not found"): the
+// message plus the RT_ERR_* class the C view of the class reports (rt_host_scene_*).
+struct SceneError : std::runtime_error {
+    int code;
+    SceneError(int code_, const std::string& message) : std::runtime_error(message), code(code_) {}
+};
 
 struct Material {
     material_type type = DIFFUSE;
@@ -91,6 +99,9 @@ struct RenderSettings {
     // not in the reference: skip clusters of triangles whose bounds a ray misses
     // (false = the reference's exhaustive triangle scan)
     bool cluster_culling = true;
+    // not in the reference: split every frame over HIP devices 0 .. devices-1 of this node
+    // (samples per pixel first, bands of rows beyond that; sums exchanged over RCCL or peer copies)
+    unsigned devices = 1;
 };
 
 class Scene {
@@ -155,6 +166,7 @@ private:
     int add_material(const Material& m);
     void release_device_scene();
     void sync_device_scene(); // uploads the scene when it changed since the last upload
+    int render_frame(const rt_camera& cam, const rt_options& opt); // on the device(s) the settings name
 
     std::vector<float> sphere_pos_, sphere_radius_;
     std::vector<int32_t> sphere_material_;
@@ -169,6 +181,8 @@ private:
     std::vector<float> image_;
     std::string scene_dir_; // directory of the last scene file, for mesh lookup
     rt_scene* device_scene_ = nullptr;
+    rt_device_group* device_group_ = nullptr; // instead of device_scene_ when settings.devices > 1
+    unsigned group_devices_ = 0;
     bool device_scene_stale_ = true;
     rt_stats stats_{};
 };

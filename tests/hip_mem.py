@@ -55,3 +55,9 @@ class DeviceBuffer:
     @property
     def address(self):
         return self.ptr.value
+
+
+def device_count():
+    n = C.c_int()
+    _ok(_hip.hipGetDeviceCount(C.byref(n)), "hipGetDeviceCount")
+    return n.value
