@@ -221,6 +221,11 @@ int rt_cast(rt_scene* scene, const rt_options* opt, uint32_t n, const float* ori
             float* out_abg);
 int rt_visible(rt_scene* scene, const rt_options* opt, uint32_t n, const float* origins,
                const float* targets, int32_t* out_visible);
+/* rt_random_cos = random_cos with CU_Vector::argmin_abs (src/raytrace.cu:253-296,
+ * include/vector.cuh:87-98) on the device, for n triples of a normal (3n
+ * floats) and the two uniforms the reference draws; out_dirs receives 3n
+ * floats.  All host arrays. */
+int rt_random_cos(uint32_t n, const float* normals, const float* r1, const float* r2, float* out_dirs);
 
 /* ---- host scene API: C view of class Scene ------------------------------
  * Mirrors the reference's public Scene interface (include/scene.cuh:8-31);

@@ -134,6 +134,7 @@ def _load() -> C.CDLL:
         "rt_host_scene_set_devices": [vp, C.c_uint32],
         "rt_cast": [vp, C.POINTER(Options), C.c_uint32, _f32p, _f32p, _f32p, _i32p, _i32p, _f32p],
         "rt_visible": [vp, C.POINTER(Options), C.c_uint32, _f32p, _f32p, _i32p],
+        "rt_random_cos": [C.c_uint32, _f32p, _f32p, _f32p, _f32p],
         "rt_host_scene_create": [C.POINTER(vp)],
         "rt_host_scene_destroy": [vp],
         "rt_host_scene_load": [vp, C.c_char_p],
@@ -177,7 +178,7 @@ EXPORTS = [
     "rt_host_scene_set_options", "rt_host_scene_render", "rt_host_scene_describe", "rt_host_scene_image",
     "rt_write_png", "rt_write_pfm", "rt_set_progress", "rt_host_scene_render_frames", "rt_accumulate_rows",
     "rt_accumulate_static", "rt_add_sums", "rt_frame_partition", "rt_device_group_create", "rt_device_group_render",
-    "rt_device_group_free", "rt_host_scene_set_devices",
+    "rt_device_group_free", "rt_host_scene_set_devices", "rt_random_cos",
 ]
 
 
@@ -356,6 +357,16 @@ def frame_partition(rank: int, world: int, spp: int, height: int) -> Tuple[int, 
 
 def add_sums(d_dst_ptr: int, d_src_ptr: int, n_floats: int, stream: int = 0) -> None:
     _check(lib.rt_add_sums(C.c_void_p(d_dst_ptr), C.c_void_p(d_src_ptr), n_floats, C.c_void_p(stream)))
+
+
+def random_cos(normals, r1, r2) -> np.ndarray:
+    """rt_random_cos: the device's cosine-weighted direction for every (normal, r1, r2)."""
+    nrm = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+    a = np.ascontiguousarray(r1, dtype=np.float32)
+    b = np.ascontiguousarray(r2, dtype=np.float32)
+    out = np.empty_like(nrm)
+    _check(lib.rt_random_cos(len(nrm), _fptr(nrm), _fptr(a), _fptr(b), _fptr(out)))
+    return out
 
 
 def resolve(d_sum_ptr: int, n_pixels: int, d_out_ptr: int, stream: int = 0) -> None:

@@ -734,6 +734,15 @@ __global__ __launch_bounds__(kBlock) void k_add_sums(float4* __restrict__ dst, c
 
 // ------------------------------------------- known-answer test kernels
 
+// random_cos for n (normal, r1, r2) triples: the function k_shade and k_trace_spheres call
+__global__ __launch_bounds__(kBlock) void k_probe_random_cos(uint32_t n, const float* __restrict__ normals, const float* __restrict__ r1,
+                                                             const float* __restrict__ r2, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const V3 d = random_cos(r1[i], r2[i], mk(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]));
+    out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
+}
+
 // rays -> state + queue, through the same launch_ray the renderer uses
 __global__ __launch_bounds__(kBlock) void k_probe_rays(DeviceScene sc, Work w, Frame f, const float* __restrict__ origins,
                                                        const float* __restrict__ dirs, int as_segments) {

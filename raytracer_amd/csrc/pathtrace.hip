@@ -1043,6 +1043,25 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
 
 } // namespace
 
+extern "C" int rt_random_cos(uint32_t n, const float* normals, const float* r1, const float* r2, float* out_dirs) {
+    if (n && (!normals || !r1 || !r2 || !out_dirs)) { rt_set_error("rt_random_cos: null argument"); return RT_ERR_INVALID; }
+    if (n == 0) return RT_OK;
+    float* d = nullptr; // normals (3n) | r1 (n) | r2 (n) | out (3n)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * 8 * sizeof(float)));
+    int rc = RT_OK;
+    if (hipMemcpy(d, normals, (size_t)n * 12, hipMemcpyHostToDevice) || hipMemcpy(d + 3 * (size_t)n, r1, (size_t)n * 4, hipMemcpyHostToDevice) ||
+        hipMemcpy(d + 4 * (size_t)n, r2, (size_t)n * 4, hipMemcpyHostToDevice)) {
+        rc = RT_ERR_DEVICE;
+    } else {
+        hipLaunchKernelGGL(k_probe_random_cos, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, n, (const float*)d,
+                           (const float*)(d + 3 * (size_t)n), (const float*)(d + 4 * (size_t)n), d + 5 * (size_t)n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out_dirs, d + 5 * (size_t)n, (size_t)n * 12, hipMemcpyDeviceToHost)) rc = RT_ERR_DEVICE;
+    }
+    if (rc != RT_OK) rt_set_error("rt_random_cos: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(d);
+    return rc;
+}
+
 extern "C" int rt_cast(rt_scene* s, const rt_options* opt, uint32_t n, const float* origins, const float* dirs, float* out_t,
                        int32_t* out_sphere, int32_t* out_triangle, float* out_abg) {
     if (n && (!out_t || !out_sphere || !out_triangle)) { rt_set_error("rt_cast: null output"); return RT_ERR_INVALID; }

@@ -186,3 +186,29 @@ def test_axis_parallel_rays_through_the_cluster_filter(pairs, monkeypatch):
     # the same rays as shadow segments
     vis = dev.visible(opt, o, o + 100 * d)
     assert np.array_equal(vis, ob.visible(desc, ob.from_rt_options(opt), o, o + 100 * d))
+
+
+def test_random_cos_matches_oracle_including_the_argmin_quirk():
+    """random_cos on the device against the oracle's, bit for bit: random normals, normals with a negative
+    x (the reference's argmin_abs starts its running minimum at the SIGNED first component, so it answers 0
+    whenever N.x < 0, include/vector.cuh:87-98), axis-aligned normals, and N = (-1, 0, 0), whose tangent is
+    the zero vector: the direction is NaN and the path ends."""
+    rng = np.random.default_rng(3)
+    n = 4096
+    normals = rng.normal(size=(n, 3)).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    special = np.array([[-1, 0, 0], [1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [-0.6, 0.8, 0], [-0.6, 0, 0.8],
+                        [-1e-3, 0.6, 0.8], [0.6, -0.8, 0], [0.57735026, 0.57735026, 0.57735026]], np.float32)
+    normals[:len(special)] = special
+    r1 = rng.uniform(0, 1, n).astype(np.float32)
+    r2 = rng.uniform(0, 1, n).astype(np.float32)
+    r1[20:24] = [1.0, 5.9604645e-08, 0.25, 0.5]  # the ends of the generator's (0, 1] range
+    r2[24:28] = [1.0, 5.9604645e-08, 1.0, 0.5]
+    got = rt.random_cos(normals, r1, r2)
+    want = ob.random_cos(normals, r1, r2)
+    assert np.isnan(got[0]).all() and np.isnan(want[0]).all()  # N = (-1, 0, 0)
+    assert same_bits(got, want)
+    finite = ~np.isnan(got).any(axis=1)
+    assert finite.sum() >= n - 1
+    np.testing.assert_allclose(np.linalg.norm(got[finite], axis=1), 1.0, atol=2e-6)
+    assert (np.einsum("ij,ij->i", got[finite], normals[finite]) >= -1e-6).all()  # in the hemisphere of N
