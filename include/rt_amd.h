@@ -142,7 +142,12 @@ int rt_render(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
  * d_sum (DEVICE memory, 4 * width * height floats: r, g, b, actual_rays),
  * in sample order.  rt_resolve turns such a buffer -- after the per-device
  * buffers were summed -- into the output image on the device.  `stream` is
- * a hipStream_t (NULL = default stream); both calls only enqueue work. */
+ * a hipStream_t (NULL = default stream); both calls only enqueue work.
+ * A NEGATIVE sample count marks a pixel whose sample loop the reference ends
+ * after the sample just added (terminate_early, src/raytrace.cu:340-346,
+ * 496-498: direct light without anti-aliasing, diffuse first hit): later
+ * calls on the same buffer leave the pixel alone, rt_resolve divides by the
+ * magnitude. */
 int rt_accumulate(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
                   uint32_t sample_begin, uint32_t sample_end, float* d_sum,
                   void* stream, rt_stats* stats);

@@ -539,7 +539,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
     const uint32_t ux = pixel % f.width, uy = pixel / f.width;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!buffered && real) acc = sum[pixel];
-    bool done = !real; // the reference's terminate_early: the sample loop of this pixel has ended
+    // the reference's terminate_early: the sample loop of this pixel has ended (in an earlier call
+    // if the count arrives negative, see k_accumulate)
+    bool done = !real || acc.w < 0.f;
+    const bool ended_before = done;
     uint32_t n_casts = 0;
     const V3 eye = mk(f.pos[0], f.pos[1], f.pos[2]);
 
@@ -670,7 +673,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
             }
         }
     }
-    if (!buffered && real) sum[pixel] = acc;
+    if (!buffered && real && !ended_before) {
+        if (done) acc.w = -acc.w;
+        sum[pixel] = acc;
+    }
     if (f.count_casts && n_casts && __lane_id() == 0) {
         const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kCastShards;
         atomicAdd(&cast_count[(size_t)shard * kCountStride], n_casts);
@@ -685,6 +691,9 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DeviceScene sc, Work w, F
     if (pixel >= f.n_pixels) return;
     float4 acc = sum[f.pixel_offset + pixel];
     const uint32_t n_samples = f.n_paths / f.n_pixels;
+    // A negative sample count marks a pixel whose sample loop the reference has ended
+    // (terminate_early, src/raytrace.cu:340-346,496-498): later batches and sample ranges add nothing.
+    if (acc.w < 0.f) return;
     // four records are requested at a time (the additions themselves stay in sample order)
     bool done = false;
     for (uint32_t s0 = 0; s0 < n_samples && !done; s0 += 4) {
@@ -705,6 +714,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DeviceScene sc, Work w, F
             if (!f.indirect && (flags & F_EARLY)) done = true;
         }
     }
+    if (done) acc.w = -acc.w;
     sum[f.pixel_offset + pixel] = acc;
 }
 
@@ -713,7 +723,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ s
     const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
     if (pixel >= n_pixels) return;
     const float4 s = sum[pixel];
-    const float inv = 1.f / s.w;
+    const float inv = 1.f / fabsf(s.w); // the sign only says that the pixel's sample loop ended early
     out[3 * pixel + 0] = rt_gamma_encode(inv * s.x);
     out[3 * pixel + 1] = rt_gamma_encode(inv * s.y);
     out[3 * pixel + 2] = rt_gamma_encode(inv * s.z);

@@ -382,6 +382,30 @@ def test_three_lights_with_glass_mesh():
     assert same_bits(img, ref)
 
 
+@pytest.mark.parametrize("scene", ["mesh_scene", "default"])
+def test_early_termination_holds_across_calls(scene):
+    """Direct light without anti-aliasing: a pixel whose first sample hits a diffuse surface ends its sample
+    loop there (reference src/raytrace.cu:340-346,496-498).  Sample ranges added one call after the other must
+    keep it ended -- the count stays at one sample, carried as -1 -- and give the oracle's image."""
+    from hip_mem import DeviceBuffer
+
+    s = load(scene, 80, 60, 5)
+    desc, cam = s.describe()
+    dev = s.upload()
+    opt = rt.make_options(indirect=False, antialiasing=False, seed=19)
+    n = cam.width * cam.height
+    parts, whole, out = DeviceBuffer(4 * n), DeviceBuffer(4 * n), DeviceBuffer(3 * n)
+    for b, e in [(0, 1), (1, 3), (3, 5)]:
+        dev.accumulate(cam, opt, b, e, parts.address)
+    dev.accumulate(cam, opt, 0, 5, whole.address)
+    p, w = parts.to_host().reshape(-1, 4), whole.to_host().reshape(-1, 4)
+    assert np.array_equal(p.view(np.uint32), w.view(np.uint32))
+    assert set(np.unique(p[:, 3])) <= {-1.0, 5.0} and (p[:, 3] == -1.0).mean() > 0.5
+    rt.resolve(parts.address, n, out.address)
+    ref, _ = ob.render_image(desc, cam, ob.from_rt_options(opt))
+    assert same_bits(out.to_host().reshape(ref.shape), ref)
+
+
 def test_zero_length_sample_range_adds_nothing():
     from hip_mem import DeviceBuffer
 
