@@ -70,9 +70,14 @@ RT_HD rt_rng_key rt_rng_make_key(uint32_t seed, uint32_t pixel, uint32_t sample)
     return k;
 }
 
-/* The dim-th 32-bit word of a path's stream. */
+/* The dim-th 32-bit word of a path's stream.  The dimension enters by XOR and
+ * the sample key by addition: with both combined the same way (say kp + dim *
+ * c) two pixels whose keys differ by a multiple j * c would draw the same
+ * stream j dimensions apart, and among a few hundred thousand pixels such
+ * pairs exist.  (kp ^ dim * c) == (kp' ^ (dim + j) * c) cannot hold along a
+ * run of dimensions. */
 RT_HD uint32_t rt_rng_word(rt_rng_key k, uint32_t dim) {
-    return rt_mix32((k.kp + dim * 0x9e3779b9U) ^ k.ks);
+    return rt_mix32((k.kp ^ (dim * 0x9e3779b9U)) + k.ks);
 }
 
 /* Uniform in (0,1]: ((w>>8)+1) * 2^-24.  Every value is exactly representable,
