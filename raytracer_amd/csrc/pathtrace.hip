@@ -688,7 +688,18 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         f.n_paths = in_batch * n_pixels;
         f.sample_begin = sample_begin + first;
         const dim3 grid((f.n_paths + kBlock - 1) / kBlock), block(kBlock);
-        HIP_TRY(hipMemsetAsync(w.q_count, 0, ws.counter_words * sizeof(uint32_t), stream));
+        if (ws.n_counters == n_counters) { // the counters are one block: one fill
+            HIP_TRY(hipMemsetAsync(w.q_count, 0, ws.counter_words * sizeof(uint32_t), stream));
+        } else { // a work set laid out for more bounces than this frame has: only the stages it runs
+            const size_t q_bytes = (size_t)n_counters * kShards * kCountStride * sizeof(uint32_t);
+            HIP_TRY(hipMemsetAsync(w.q_count, 0, q_bytes, stream));
+            HIP_TRY(hipMemsetAsync(w.live_count, 0, q_bytes, stream));
+            if (cull) {
+                const size_t slots = (size_t)n_counters * ws.tiles * kCountStride * sizeof(uint32_t);
+                HIP_TRY(hipMemsetAsync(w.cl_count, 0, slots * s->d.n_clusters, stream));
+                if (s->d.n_groups) HIP_TRY(hipMemsetAsync(w.grp_count, 0, slots * s->d.n_groups, stream));
+            }
+        }
         if (stats) HIP_TRY(hipMemsetAsync(w.cast_count, 0, cast_counts.size() * sizeof(uint32_t), stream));
         // paths per lane: as many as still leave 2 048 workgroups (8 per CU)
         if (f.n_paths >= 2048u * kBlock * 4)

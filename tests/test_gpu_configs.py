@@ -295,6 +295,19 @@ def test_bounce_limits(depth):
         assert not img.any()
 
 
+def test_shallower_frame_on_a_handle_that_rendered_a_deeper_one():
+    """The work buffers keep the layout of the deepest frame rendered so far; a frame with fewer bounces
+    then clears and uses only the stages it runs."""
+    s = load("mesh_scene", 64, 48, 3)
+    desc, cam = s.describe()
+    dev = s.upload()
+    for depth in (7, 2, 5, 1):
+        opt = rt.make_options(max_depth=depth, seed=12)
+        img, _ = dev.render(cam, opt)
+        ref, _ = ob.render_image(desc, cam, ob.from_rt_options(opt))
+        assert same_bits(img, ref), f"depth {depth}"
+
+
 def test_empty_scene_and_scene_without_lights():
     s = rt.Scene()
     s.set_camera_intrinsics(60.0, 32, 16)
