@@ -25,6 +25,8 @@ constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
 constexpr uint32_t kMaxLights = 64;
 constexpr uint32_t kClusterPairs = 8;       // triangle pairs per culling cluster of a small mesh (16 triangles; swept 4-32 on the cat mesh)
 constexpr uint32_t kMaxClusters = 64 * 64;  // two levels of at most 64 boxes each; larger meshes get larger clusters
+constexpr uint32_t kFusedGroup = 16;        // clusters per group at most where k_group_clusters is used ...
+constexpr uint32_t kFusedMaxGroups = 64;    // ... which is for meshes of up to 64 such groups
 constexpr size_t kClusterListBudget = size_t(24) << 30; // most bytes the per-cluster ray lists may take (of 288 GB)
 
 constexpr uint32_t kLivePending = 0x80000000u; // in an entry of the live-path list: the path has F_PENDING set
@@ -57,6 +59,7 @@ struct DeviceScene {
     const float4* light;      // position.xyz, intensity
     uint32_t n_spheres, n_triangles, n_boxes, n_lights, n_materials;
     uint32_t n_clusters, cluster_pairs, n_groups, group_clusters;
+    uint32_t fused_groups; // groups of at most 16 clusters: k_group_clusters bins and scans them in one kernel
 };
 
 // Per-batch path state and queues.

@@ -490,6 +490,150 @@ __global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl
     }
 }
 
+// ---- second level and triangle scan in one kernel ---------------------------
+//
+// For meshes of up to kFusedMaxGroups * kFusedGroup clusters the groups hold at most kFusedGroup
+// clusters each, and the rays on a group's list are binned into that group's clusters IN LDS and
+// scanned against the clusters' triangles by the same workgroup: no per-cluster lists in global
+// memory (they were the bulk of a scene handle's footprint), no global reservations, no job table,
+// and one kernel less per triangle stage.
+//
+// A workgroup of T threads takes a contiguous run of one group's list (a few passes of R * T
+// entries).  Per pass: every lane tests its entries' rays against the group's cluster boxes and
+// appends, per touched cluster, a 16-bit reference to the ray into that cluster's LDS list; then
+// the wavefronts take (cluster, 64 references) jobs -- the pair scan of k_mesh over the cluster's
+// triangle pairs -- as long as full jobs are left.  What remains of a list (fewer than 64
+// references) is carried into the next pass, so the lanes of a job are all busy except in the run's
+// last pass, which scans the partial jobs too.
+template <int R, int T>
+__global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
+                                                      uint32_t n_clusters, uint32_t cluster_pairs, uint32_t n_groups,
+                                                      uint32_t group_clusters, const f2* __restrict__ cl_pair,
+                                                      const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                      const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_list,
+                                                      uint32_t list_capacity, unsigned long long* __restrict__ hit,
+                                                      uint32_t* __restrict__ cl_stat) {
+    constexpr uint32_t kPass = R * T;                    // list entries per pass
+    constexpr uint32_t kWaves = T / 64;
+    constexpr uint32_t kListLen = kPass + 64;            // references a cluster's list can hold: a pass plus what was carried
+    static_assert(kPass + kFusedGroup * 64 <= 65536, "references are 16 bits wide");
+    __shared__ uint16_t list[kFusedGroup][kListLen];     // per cluster: references into at[]
+    __shared__ uint32_t at[kPass + kFusedGroup * 64];    // queue positions: this pass's entries, then 64 carried slots per cluster
+    __shared__ uint32_t cnt[kFusedGroup];                // length of each cluster's list
+    __shared__ uint32_t first_run[kFusedMaxGroups + 1];  // runs of the groups before each group
+    __shared__ uint32_t run_entries_s;
+
+    // ---- plan: the groups' lists are cut into runs of `run_entries` entries (a multiple of kPass),
+    // sized so that every workgroup of the grid gets about one run; every workgroup computes the same plan
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        const uint32_t mine = lane < n_groups ? grp_count[lane * kCountStride] : 0;
+        uint32_t total = mine;
+#pragma unroll
+        for (int step = 1; step < 64; step <<= 1) total += __shfl_xor(total, step);
+        uint32_t passes = (total + gridDim.x * kPass - 1) / (gridDim.x * kPass);
+        passes = min(max(passes, 1u), 16u);
+        const uint32_t run_entries = passes * kPass;
+        const uint32_t runs = (mine + run_entries - 1) / run_entries;
+        uint32_t incl = runs;
+#pragma unroll
+        for (int step = 1; step < 64; step <<= 1) {
+            const uint32_t up = __shfl_up(incl, step);
+            if ((int)lane >= step) incl += up;
+        }
+        if (lane < n_groups) first_run[lane] = incl - runs;
+        if (lane == 63) first_run[n_groups] = incl; // lanes past n_groups add nothing: the total
+        if (lane == 0) run_entries_s = run_entries;
+    }
+    __syncthreads();
+    const uint32_t n_runs = first_run[n_groups], run_entries = run_entries_s;
+    const uint32_t n_pairs = (n_tri + 1) / 2;
+
+    for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
+        // the group this run belongs to (first_run is non-decreasing; n_groups <= 64: one ballot)
+        const uint32_t fr = lane < n_groups ? first_run[lane] : 0xffffffffu;
+        const uint32_t g = (uint32_t)__popcll(__ballot(fr <= run)) - 1u;
+        const uint32_t count = grp_count[g * kCountStride];
+        const uint32_t run_begin = (run - first_run[g]) * run_entries;
+        const uint32_t run_end = min(run_begin + run_entries, count);
+        const uint32_t first_cluster = g * group_clusters; // even: a group starts a box pair
+        const uint32_t boxes = min(group_clusters, n_clusters - first_cluster);
+        const uint32_t real = (1u << boxes) - 1u;          // an odd count leaves half a box pair without a box
+        const uint32_t* __restrict__ my_list = grp_list + (size_t)g * list_capacity;
+        if (threadIdx.x < kFusedGroup) cnt[threadIdx.x] = 0;
+        uint32_t carried = 0; // threads 0..15: references their cluster's list held before this pass
+        __syncthreads();
+
+        for (uint32_t pass = run_begin; pass < run_end; pass += kPass) {
+            // ---- bin this pass's entries into the clusters' lists
+            SlabRay ray[R];
+            bool active[R];
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                const uint32_t e = pass + i * T + threadIdx.x;
+                active[i] = e < run_end;
+                const uint32_t pos = my_list[active[i] ? e : run_end - 1];
+                at[i * T + threadIdx.x] = pos;
+                ray[i] = slab_ray(q_o[2 * (size_t)pos], q_d[2 * (size_t)pos]);
+            }
+            uint32_t bits[R];
+            slab_bits<R>(cl_pair + 6 * (size_t)(first_cluster / 2), 0, (boxes + 1) / 2, ray, bits);
+#pragma unroll
+            for (int i = 0; i < R; i++)
+                for (uint32_t m = active[i] ? (bits[i] & real) : 0u; m; m &= m - 1) {
+                    const uint32_t c = (uint32_t)__ffs((int)m) - 1u;
+                    list[c][atomicAdd(&cnt[c], 1u)] = (uint16_t)(i * T + threadIdx.x);
+                }
+            __syncthreads();
+            // ---- scan: (cluster, 64 references) jobs, full ones only unless this is the run's last pass
+            const bool last = pass + kPass >= run_end;
+            const uint32_t len = lane < boxes ? cnt[lane] : 0;
+            if (cl_stat && threadIdx.x < boxes) // statistics: ray-cluster pairs listed in this pass
+                atomicAdd(&cl_stat[(size_t)(first_cluster + threadIdx.x) * kCountStride], len - carried);
+            const uint32_t jobs = last ? (len + 63) / 64 : len / 64;
+            uint32_t incl = jobs;
+#pragma unroll
+            for (int step = 1; step < (int)kFusedGroup; step <<= 1) {
+                const uint32_t up = __shfl_up(incl, step);
+                if ((int)lane >= step) incl += up;
+            }
+            const uint32_t before = incl - jobs;                 // lanes 0..15: jobs of the clusters before mine
+            const uint32_t n_jobs = __shfl(incl, kFusedGroup - 1);
+            for (uint32_t j = wave; j < n_jobs; j += kWaves) {
+                const uint32_t c = (uint32_t)__popcll(__ballot(lane < kFusedGroup && before <= j)) - 1u;
+                const uint32_t entry = (j - __shfl(before, (int)c)) * 64 + lane;
+                const bool valid = entry < __shfl(len, (int)c);
+                const uint32_t pos = at[list[c][valid ? entry : 0]];
+                const float4 o4 = q_o[2 * (size_t)pos];
+                const float4 d4 = q_d[2 * (size_t)pos];
+                Nearest best = nearest_init(d4.w);
+                const uint32_t first = (first_cluster + c) * cluster_pairs;
+                scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
+                if (valid && best.index >= 0) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | tri_orig[best.index];
+                    atomicMin(&hit[__float_as_uint(o4.w)], key);
+                }
+            }
+            __syncthreads();
+            // ---- carry: the references past the last full job move to the front of their list, their
+            // queue positions into the cluster's carried slots (a wavefront per cluster: it reads before it writes)
+            for (uint32_t c = wave; c < boxes; c += kWaves) {
+                const uint32_t n = cnt[c];
+                const uint32_t keep = last ? 0 : n % 64;
+                uint32_t pos = 0;
+                if (lane < keep) pos = at[list[c][n - keep + lane]];
+                if (lane < keep) {
+                    at[kPass + c * 64 + lane] = pos;
+                    list[c][lane] = (uint16_t)(kPass + c * 64 + lane);
+                }
+                if (lane == 0) cnt[c] = keep;
+            }
+            if (threadIdx.x < kFusedGroup) carried = last ? 0 : len % 64;
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
                                                           uint32_t n_clusters, uint32_t cluster_pairs,
                                                           const float4* __restrict__ q_o, const float4* __restrict__ q_d,

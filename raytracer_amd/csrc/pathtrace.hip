@@ -201,11 +201,12 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     if (queue_entries > 0xffffffffu) { rt_set_error("batch too large for the ray queue"); return RT_ERR_INVALID; }
     // cluster lists: one tile of rays at a time if the whole queue would not fit the budget
     const size_t nc = d.n_clusters, ng = d.n_groups;
+    const size_t lists_nc = d.fused_groups ? 0 : nc; // k_group_clusters keeps the per-cluster lists in LDS
     size_t list_capacity = 0, tiles = 1;
     if (nc > 1) {
         // a tile is a range of 256-ray blocks; every shard may end in a partial block
         const size_t max_blocks = ((shard_capacity + kBlock - 1) / kBlock) * kShards;
-        list_capacity = list_budget / (4 * (nc + ng)) / kBlock * kBlock;
+        list_capacity = list_budget / (4 * (lists_nc + ng)) / kBlock * kBlock;
         if (list_capacity > max_blocks * kBlock) list_capacity = max_blocks * kBlock;
         if (list_capacity < kBlock) list_capacity = kBlock;
         tiles = (max_blocks + list_capacity / kBlock - 1) / (list_capacity / kBlock);
@@ -233,7 +234,7 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     w.grp_count = w.cl_count + cl_words;
     w.live = c.take<uint32_t>(2 * kShards * live_capacity);
     w.cast_count = c.take<uint32_t>((size_t)n_counters * kCastShards * kCountStride);
-    w.cl_list = c.take<uint32_t>(nc * list_capacity);
+    w.cl_list = c.take<uint32_t>(lists_nc * list_capacity);
     w.grp_list = c.take<uint32_t>(ng * list_capacity);
     w.live_total = (uint32_t)live_total;
     w.live_capacity = (uint32_t)live_capacity;
@@ -308,7 +309,8 @@ int mark_event(rt_scene* s, hipStream_t stream, char tag) {
 
 // One k_mesh stage: the queued rays of `counter` against the mesh, either by
 // the exhaustive scan or through the cluster lists.
-int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t stream, bool profile, bool cull, uint32_t batch_paths) {
+int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t stream, bool profile, bool cull, uint32_t batch_paths,
+                bool count_tests) {
     const Work& w = ws.w;
     if (s->d.n_triangles == 0) return RT_OK;
     auto mark = [&](char tag) -> int { return profile ? mark_event(s, stream, tag) : RT_OK; };
@@ -337,25 +339,36 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
             if (forced == 2) { wide = true; wider = false; }
             if (forced == 4) wide = wider = true;
             auto bin64 = wider ? k_bin64<4> : wide ? k_bin64<2> : k_bin64<1>;
-            if (s->d.n_groups == 0) {
-                hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, cl_pair, nc,
-                                   (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
-                                   tile * blocks_per_tile, blocks_per_tile, cl_count, w.cl_list, w.list_capacity);
+            const uint32_t ng = s->d.n_groups;
+            uint32_t* grp_count = w.grp_count + slot * ng * kCountStride;
+            hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
+                               (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
+                               tile * blocks_per_tile, blocks_per_tile, grp_count, w.grp_list, w.list_capacity);
+            if (s->d.fused_groups) {
+                // second level and triangle scan in one kernel: the per-cluster lists live in LDS
+                if ((rc = mark('M')) != RT_OK) return rc;
+                static const int fused_rays = [] { const char* e = std::getenv("RT_AMD_FUSED_RAYS"); return e ? std::atoi(e) : 0; }(); // tuning knob
+                static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }();
+                static const int fused_threads = [] { const char* e = std::getenv("RT_AMD_FUSED_THREADS"); return e ? std::atoi(e) : 0; }();
+                const uint32_t threads = fused_threads == 512 ? 512 : fused_threads == 1024 ? 1024 : 256;
+                auto group_clusters = threads == 512 ? (fused_rays == 1 ? k_group_clusters<1, 512> : k_group_clusters<2, 512>)
+                                      : threads == 1024 ? k_group_clusters<1, 1024>
+                                      : fused_rays == 4 ? k_group_clusters<4, 256> : fused_rays == 1 ? k_group_clusters<1, 256> : k_group_clusters<2, 256>;
+                hipLaunchKernelGGL(group_clusters, dim3(fused_grid > 0 ? (uint32_t)fused_grid : cl_grid), dim3(threads), 0, stream,
+                                   tri2, s->d.tri_orig, s->d.n_triangles, nc,
+                                   s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
+                                   (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,
+                                   count_tests ? cl_count : (uint32_t*)nullptr);
             } else {
-                const uint32_t ng = s->d.n_groups;
-                uint32_t* grp_count = w.grp_count + slot * ng * kCountStride;
-                hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
-                                   (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
-                                   tile * blocks_per_tile, blocks_per_tile, grp_count, w.grp_list, w.list_capacity);
                 auto bin_groups = wider ? k_bin_groups<4> : wide ? k_bin_groups<2> : k_bin_groups<1>;
                 hipLaunchKernelGGL(bin_groups, dim3(bin_grid), dim3(kBlock), 0, stream, cl_pair, nc, ng, s->d.group_clusters,
                                    (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)grp_count,
                                    (const uint32_t*)w.grp_list, cl_count, w.cl_list, w.list_capacity);
+                if ((rc = mark('M')) != RT_OK) return rc;
+                hipLaunchKernelGGL(k_mesh_clusters, dim3(cl_grid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
+                                   s->d.cluster_pairs, (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)cl_count,
+                                   (const uint32_t*)w.cl_list, w.list_capacity, w.hit);
             }
-            if ((rc = mark('M')) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_mesh_clusters, dim3(cl_grid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
-                               s->d.cluster_pairs, (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)cl_count,
-                               (const uint32_t*)w.cl_list, w.list_capacity, w.hit);
             if ((rc = mark('E')) != RT_OK) return rc;
         }
     } else {
@@ -550,14 +563,17 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
             if (c & 1) dst.y = v[k]; else dst.x = v[k];
         }
     }
-    // groups of consecutive clusters with the union of their bounds: about sqrt(n) groups of
-    // sqrt(n) clusters (an even number, so that a group starts a box pair), at most 64 of at most 64
-    uint32_t group_clusters = 2 * (((uint32_t)std::ceil(std::sqrt((double)n_clusters)) + 1) / 2);
+    // Groups of consecutive clusters with the union of their bounds.  Up to kFusedMaxGroups * kFusedGroup
+    // clusters: groups of kFusedGroup clusters, binned and scanned by one kernel (k_group_clusters).
+    // Beyond: about sqrt(n) groups of sqrt(n) clusters (an even number, so that a group starts a box
+    // pair), at most 64 of at most 64, with per-cluster lists in global memory.
+    const bool fused = n_clusters > 1 && n_clusters <= kFusedMaxGroups * kFusedGroup;
+    uint32_t group_clusters = fused ? kFusedGroup : 2 * (((uint32_t)std::ceil(std::sqrt((double)n_clusters)) + 1) / 2);
     if (const char* env = std::getenv("RT_AMD_GROUP_CLUSTERS")) { // tuning / test knob
         const long v = std::strtol(env, nullptr, 10);
-        if (v >= 2 && v <= 64 && v % 2 == 0 && (n_clusters + v - 1) / v <= 64) group_clusters = (uint32_t)v;
+        if (v >= 2 && v <= (fused ? (long)kFusedGroup : 64) && v % 2 == 0 && (n_clusters + v - 1) / v <= 64) group_clusters = (uint32_t)v;
     }
-    const uint32_t n_groups = n_clusters > 64 ? (n_clusters + group_clusters - 1) / group_clusters : 0;
+    const uint32_t n_groups = n_clusters > 1 ? (n_clusters + group_clusters - 1) / group_clusters : 0;
     std::vector<float2> grp_pair(6 * (((size_t)n_groups + 1) / 2), make_float2(0.f, 0.f));
     for (uint32_t g = 0; g < n_groups; g++) {
         float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -591,6 +607,7 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     s->d.cluster_pairs = cluster_pairs;
     s->d.n_groups = n_groups;
     s->d.group_clusters = group_clusters;
+    s->d.fused_groups = fused ? 1u : 0u;
     s->cluster_tris = cluster_tris;
     if ((rc = upload(s, sphere, &s->d.sphere)) || (rc = upload(s, sphere_mat, &s->d.sphere_mat)) ||
         (rc = upload(s, mat_color, &s->d.mat_color)) || (rc = upload(s, mat_ior, &s->d.mat_ior)) ||
@@ -710,13 +727,13 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             hipLaunchKernelGGL(k_generate<1>, grid, block, 0, stream, s->d, w, f);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
-            if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
+            if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
             hipLaunchKernelGGL(k_shade, depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
         }
-        if ((rc = launch_mesh(s, ws, (uint32_t)opt->max_depth, stream, profile, cull, f.n_paths)) != RT_OK) return rc;
+        if ((rc = launch_mesh(s, ws, (uint32_t)opt->max_depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
         hipLaunchKernelGGL(k_accumulate, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, s->d, w, f,
                            reinterpret_cast<float4*>(d_sum));
         HIP_TRY(hipGetLastError());
@@ -1028,7 +1045,7 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
         const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
         if (cull && hipMemset(w.cl_count, 0, (size_t)2 * s->ws.tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         if (cull && s->d.n_groups && hipMemset(w.grp_count, 0, (size_t)2 * s->ws.tiles * s->d.n_groups * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
-        if (launch_mesh(s, s->ws, 0, nullptr, false, cull, n) != RT_OK) { rc = RT_ERR_DEVICE; break; }
+        if (launch_mesh(s, s->ws, 0, nullptr, false, cull, n, false) != RT_OK) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }
         if (as_segments) {
