@@ -1,4 +1,4 @@
-// mesh_kernels.hip.h -- the triangle kernels: exhaustive scan (k_mesh) and cluster culling (k_bin64, k_bin_groups, k_mesh_clusters).
+// mesh_kernels.hip.h -- the triangle kernels: exhaustive scan (k_mesh) and cluster culling (k_bin64, then k_group_clusters, or k_bin_groups + k_mesh_clusters for very large meshes).
 // Part of the device half of librt_amd.so; included by pathtrace.hip only.
 #pragma once
 
@@ -234,20 +234,25 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
 //
 // The reference tests every triangle once any object box is hit
 // (src/raytrace.cu:136-148).  A triangle can only be hit by a ray that passes
-// through the (padded) bounds of the cluster of 64 spatially adjacent
-// triangles it belongs to, before the ray's cut-off distance.  k_bin64 lists,
-// per cluster, the queued rays that do; k_mesh_clusters turns the list lengths
-// into job offsets (plan_jobs) and runs the same pair scan as k_mesh over each
-// cluster's list.  A mesh of more than 64 clusters gets a second level: groups
-// of about sqrt(n) consecutive clusters (neighbours in space, the triangles
-// being in Morton order; at most 64 groups of at most 64) with the union of
-// their bounds; k_bin64 lists the rays per group and k_bin_groups bins each
-// group's list into its clusters, so a ray is tested against the groups and
-// the clusters of the groups it enters instead of against every cluster -- a
-// two-level bounding-volume hierarchy walked breadth first.  The image is the exhaustive scan's, bit for bit, unless the
-// reference's own rounding makes it accept a triangle for a ray that misses
-// the triangle by more than the padding (a grazing ray whose barycentrics are
-// rounding noise); rt_options.cluster_culling = 0 selects the exhaustive scan.
+// through the (padded) bounds of the cluster of 16 or 32 spatially adjacent
+// triangles it belongs to, before the ray's cut-off distance.  The clusters are
+// put into groups of consecutive clusters (neighbours in space, the triangles
+// being in Morton order) with the union of their bounds -- a two-level
+// bounding-volume hierarchy walked breadth first:
+//
+//   k_bin64            every queued ray against the (at most 64) group boxes
+//                      -> per-group lists of queue positions in global memory
+//   k_group_clusters   meshes of up to 64 groups of 16 clusters: a workgroup
+//                      bins a stretch of one group's list into that group's
+//                      clusters in LDS and scans the clusters' triangles itself
+//   k_bin_groups +     larger meshes (groups of up to 64 clusters): per-cluster
+//   k_mesh_clusters    lists in global memory, job offsets from the list
+//                      lengths (plan_jobs), the same pair scan per job
+//
+// The image is the exhaustive scan's, bit for bit, unless the reference's own
+// rounding makes it accept a triangle for a ray that misses the triangle by
+// more than the padding (a grazing ray whose barycentrics are rounding noise);
+// rt_options.cluster_culling = 0 selects the exhaustive scan.
 
 // Index of the last entry of first[0..n) that is <= job (entries are
 // non-decreasing; empty ranges share their successor's value).

@@ -3,7 +3,7 @@
 // rt_cast, rt_visible).  The gfx950 kernels live in three headers:
 //
 //   device_scene.hip.h   layouts in HBM, vector arithmetic, sphere / box tests, ray queue
-//   mesh_kernels.hip.h   k_mesh (exhaustive scan), k_bin64 / k_bin_groups / k_mesh_clusters (culling)
+//   mesh_kernels.hip.h   k_mesh (exhaustive scan), k_bin64 / k_group_clusters / k_bin_groups / k_mesh_clusters (culling)
 //   path_kernels.hip.h   k_generate, k_shade, k_accumulate, k_resolve, known-answer test kernels
 //
 // The reference runs one CUDA thread per pixel through the whole sample and
@@ -13,7 +13,7 @@
 //   k_generate           camera sample, nearest sphere, box test
 //   for each bounce:
 //     triangle stage     the queued rays against the mesh: k_mesh, or
-//                        k_bin64 (+ k_bin_groups) and k_mesh_clusters
+//                        k_bin64 and k_group_clusters (very large meshes: k_bin_groups, k_mesh_clusters)
 //     k_shade            hit selection, material response, shadow rays,
 //                        next ray, nearest sphere, box test
 //   triangle stage       shadow rays of the last bounce
@@ -347,14 +347,12 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
             if (s->d.fused_groups) {
                 // second level and triangle scan in one kernel: the per-cluster lists live in LDS
                 if ((rc = mark('M')) != RT_OK) return rc;
-                static const int fused_rays = [] { const char* e = std::getenv("RT_AMD_FUSED_RAYS"); return e ? std::atoi(e) : 0; }(); // tuning knob
-                static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }();
-                static const int fused_threads = [] { const char* e = std::getenv("RT_AMD_FUSED_THREADS"); return e ? std::atoi(e) : 0; }();
-                const uint32_t threads = fused_threads == 512 ? 512 : fused_threads == 1024 ? 1024 : 256;
-                auto group_clusters = threads == 512 ? (fused_rays == 1 ? k_group_clusters<1, 512> : k_group_clusters<2, 512>)
-                                      : threads == 1024 ? k_group_clusters<1, 1024>
-                                      : fused_rays == 4 ? k_group_clusters<4, 256> : fused_rays == 1 ? k_group_clusters<1, 256> : k_group_clusters<2, 256>;
-                hipLaunchKernelGGL(group_clusters, dim3(fused_grid > 0 ? (uint32_t)fused_grid : cl_grid), dim3(threads), 0, stream,
+                // 512 threads bin 1 024 list entries per pass (measured on the cat frame, 256 / 512 / 1 024 threads:
+                // 1.03 / 0.91 / 1.13 ms per frame).  Many more workgroups than fit the chip: a run is then one or
+                // two passes and the runs even out (768 / 3 072 / 6 144 workgroups: 1.20 / 0.90 / 0.87 ms).
+                static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
+                const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : batch_paths >= 6u * 1024u * 1024u ? 6144u : batch_paths >= 2u * 1024u * 1024u ? 3072u : 1024u;
+                hipLaunchKernelGGL((k_group_clusters<2, 512>), dim3(grid), dim3(512), 0, stream,
                                    tri2, s->d.tri_orig, s->d.n_triangles, nc,
                                    s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
                                    (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,

@@ -61,3 +61,11 @@ def device_count():
     n = C.c_int()
     _ok(_hip.hipGetDeviceCount(C.byref(n)), "hipGetDeviceCount")
     return n.value
+
+
+def free_bytes():
+    """Free device memory of the current device."""
+    free, total = C.c_size_t(), C.c_size_t()
+    _hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    _ok(_hip.hipMemGetInfo(C.byref(free), C.byref(total)), "hipMemGetInfo")
+    return free.value
