@@ -96,7 +96,9 @@ class Meter:
         self.frames += 1
 
     def roofline(self, kernel, step_ms, traffic):
-        """The triangle kernel: 47 flop per ray-triangle test it executed."""
+        """The triangle kernel: 47 flop per ray-triangle test it executed.  (In the default mode the kernel,
+        k_group_clusters, also bins every ray of a group into the group's clusters before it scans them; that
+        work is not counted.)"""
         achieved = self.tests * FLOP_PER_TRIANGLE_TEST / (self.mesh_ms * 1e-3) / 1e12 if self.mesh_ms > 0 else 0.0
         return {
             "bound": "valu",
@@ -297,9 +299,9 @@ def main():
         # HIP events on the launch stream around rank 0's launches on the sampling steps; algorithmic work per test as above.
         shade = meter.shade_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes), n_pixels * own_samples,
                                      traffic.get("k_shade_hbm_bytes_per_launch"))
-        mesh = meter.roofline("k_mesh_clusters", ms_per_step, traffic.get("k_mesh_clusters_hbm_bytes_per_launch"))
+        mesh = meter.roofline("k_group_clusters", ms_per_step, traffic.get("k_group_clusters_hbm_bytes_per_launch"))
         if shade is not None and shade["kernel_share_of_step"] >= (mesh["kernel_share_of_step"] or 0):
-            line["roofline"], line["roofline_k_mesh_clusters"] = shade, mesh
+            line["roofline"], line["roofline_k_group_clusters"] = shade, mesh
         else:
             line["roofline"], line["roofline_k_shade"] = mesh, shade
         line["roofline_whole_step"] = meter.frame_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes))

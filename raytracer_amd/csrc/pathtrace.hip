@@ -1021,19 +1021,15 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
     cam.height = 1;
     Frame f = make_frame(&cam, opt);
     f.n_paths = n;
-    float *d_a = nullptr, *d_b = nullptr, *d_t = nullptr, *d_abg = nullptr;
-    int32_t *d_s = nullptr, *d_tr = nullptr, *d_v = nullptr;
-    std::vector<void*> tmp;
-    auto grab = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) tmp.push_back(*p); return e; };
-    auto release = [&]() { for (void* p : tmp) (void)hipFree(p); };
-    hipError_t e = hipSuccess;
-    if ((e = grab((void**)&d_a, 3 * (size_t)n * 4)) || (e = grab((void**)&d_b, 3 * (size_t)n * 4)) || (e = grab((void**)&d_t, (size_t)n * 4)) ||
-        (e = grab((void**)&d_abg, 3 * (size_t)n * 4)) || (e = grab((void**)&d_s, (size_t)n * 4)) || (e = grab((void**)&d_tr, (size_t)n * 4)) ||
-        (e = grab((void**)&d_v, (size_t)n * 4))) {
-        release();
-        rt_set_error("probe: hipMalloc failed: %s", hipGetErrorString(e));
+    // one block for the seven arrays of the call: a (3n) | b (3n) | abg (3n) | t (n) | sphere (n) | triangle (n) | visible (n)
+    float* block_mem = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&block_mem), 13 * (size_t)n * 4) != hipSuccess) {
+        rt_set_error("probe: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
         return RT_ERR_NOMEM;
     }
+    float *d_a = block_mem, *d_b = d_a + 3 * (size_t)n, *d_abg = d_b + 3 * (size_t)n, *d_t = d_abg + 3 * (size_t)n;
+    int32_t *d_s = reinterpret_cast<int32_t*>(d_t + n), *d_tr = d_s + n, *d_v = d_tr + n;
+    auto release = [&]() { (void)hipFree(block_mem); };
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
     rc = RT_OK;
     do {
