@@ -149,14 +149,15 @@ class Meter:
                     "(hit selection, materials, IEEE divisions and square roots, the generator) is not counted as algorithmic work",
         }
 
-    def frame_roofline(self, step_ms, n_spheres, n_boxes):
-        """The whole step on the algorithmic work it executed: triangle tests, sphere tests and box tests of every ray."""
+    def frame_roofline(self, step_ms, n_spheres, n_boxes, world=1):
+        """The whole step on the algorithmic work it executed: triangle tests, sphere tests and box tests of every ray
+        (rank 0's counters times the number of ranks: the samples are split evenly), against the peak of all GPUs."""
         if not self.frames or not step_ms:
             return None
-        flop = (self.tests * FLOP_PER_TRIANGLE_TEST + self.casts * (FLOP_PER_SPHERE_TEST * n_spheres + FLOP_PER_BOX_TEST * n_boxes)) / self.frames
+        flop = world * (self.tests * FLOP_PER_TRIANGLE_TEST + self.casts * (FLOP_PER_SPHERE_TEST * n_spheres + FLOP_PER_BOX_TEST * n_boxes)) / self.frames
         achieved = flop / (step_ms * 1e-3) / 1e12
-        return {"bound": "valu", "kernel": "whole step", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None, "gflop_per_step": flop / 1e9}
+        return {"bound": "valu", "kernel": "whole step", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS * world, "unit": "TFLOP/s",
+                "frac": achieved / (PEAK_FP32_VECTOR_TFLOPS * world), "traffic": None, "gflop_per_step": flop / 1e9}
 
 
 def main():
@@ -304,7 +305,7 @@ def main():
             line["roofline"], line["roofline_k_group_clusters"] = shade, mesh
         else:
             line["roofline"], line["roofline_k_shade"] = mesh, shade
-        line["roofline_whole_step"] = meter.frame_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes))
+        line["roofline_whole_step"] = meter.frame_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes), world)
         if exhaustive is not None:
             ex_elapsed, ex_meter, ex_steps = exhaustive
             line["exhaustive_scan"] = {
