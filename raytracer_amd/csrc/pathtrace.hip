@@ -471,6 +471,17 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
             }
         }
     }
+    const size_t n_pairs = ((size_t)d->n_triangles + 1) / 2;
+    // Clusters of consecutive pairs and their bounds, padded by 0.05 plus a
+    // thousandth of the cluster's diagonal.
+    // 16 triangles per cluster up to 512 clusters, 32 beyond (measured: 3 844 and 3 954 triangles are
+    // faster with 16, 16 128 and 39 600 with 32: the binning work grows with the number of clusters)
+    uint32_t cluster_pairs = n_pairs <= 512 * kClusterPairs ? kClusterPairs : 2 * kClusterPairs;
+    if (const char* env = std::getenv("RT_AMD_CLUSTER_PAIRS")) { // tuning / test knob: pairs per cluster
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= 4096) cluster_pairs = (uint32_t)v;
+    }
+    while ((n_pairs + cluster_pairs - 1) / cluster_pairs > kMaxClusters) cluster_pairs *= 2;
     // Scan order of the triangle kernel: Morton order of the centroids, so
     // that consecutive triangles are neighbours in space and a cluster of them
     // has tight bounds.  Hits carry the caller's index (tri_orig) and ties are
@@ -502,10 +513,52 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
         std::sort(keyed.begin(), keyed.end());
         for (uint32_t i = 0; i < d->n_triangles; i++) order[i] = (uint32_t)keyed[i];
     }
+    // Then a k-d ordering on top of it: the triangles are split at the median of their centroids
+    // along the axis of largest extent, at multiples of the group size (16 clusters) while a part
+    // is larger than a group and at multiples of the cluster size below that, so that every
+    // cluster and every group of 16 consecutive clusters is a compact cell.  Clusters of
+    // consecutive Morton codes straddle the curve's jumps; the cells' bounds are tighter, so a ray
+    // touches fewer of them (cat mesh, headline frame: 37 instead of 63 triangle tests per path).
+    static const bool kd_order = [] { const char* e = std::getenv("RT_AMD_ORDER"); return !(e && std::strcmp(e, "morton") == 0); }(); // test knob
+    if (kd_order && d->n_triangles > 2 * cluster_pairs) {
+        std::vector<float> cen(3 * (size_t)d->n_triangles);
+        for (uint32_t i = 0; i < d->n_triangles; i++)
+            for (int a = 0; a < 3; a++) {
+                float c = 0.f;
+                for (int k = 0; k < 3; k++) c += d->vertices[3 * d->tri_v[3 * i + k] + a];
+                cen[3 * (size_t)i + a] = c == c ? c : 0.f; // NaN coordinates sort as 0
+            }
+        const size_t cluster_tris = 2 * (size_t)cluster_pairs, group_tris = kFusedGroup * cluster_tris;
+        std::vector<std::pair<size_t, size_t>> todo{{0, d->n_triangles}};
+        while (!todo.empty()) {
+            const auto [lo, hi] = todo.back();
+            todo.pop_back();
+            const size_t range = hi - lo;
+            if (range <= cluster_tris) continue;
+            const size_t unit = range > group_tris ? group_tris : cluster_tris;
+            const size_t units = (range + unit - 1) / unit;
+            const size_t mid = lo + (units / 2) * unit;
+            float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (size_t k = lo; k < hi; k++)
+                for (int a = 0; a < 3; a++) {
+                    const float c = cen[3 * (size_t)order[k] + a];
+                    if (c < mn[a]) mn[a] = c;
+                    if (c > mx[a]) mx[a] = c;
+                }
+            int axis = 0;
+            for (int a = 1; a < 3; a++)
+                if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+            std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](uint32_t x, uint32_t y) {
+                const float cx = cen[3 * (size_t)x + axis], cy = cen[3 * (size_t)y + axis];
+                return cx < cy || (cx == cy && x < y);
+            });
+            todo.push_back({lo, mid});
+            todo.push_back({mid, hi});
+        }
+    }
     // The same twelve numbers per triangle, interleaved two triangles at a time
     // for the packed-fp32 inner loop; an odd count is padded with an all-zero
     // triangle, whose zero denominator can never produce a hit.
-    const size_t n_pairs = ((size_t)d->n_triangles + 1) / 2;
     std::vector<float2> pair(12 * n_pairs, make_float2(0.f, 0.f));
     std::vector<uint32_t> orig(2 * n_pairs, 0xffffffffu);
     for (uint32_t pos = 0; pos < d->n_triangles; pos++) {
@@ -518,16 +571,6 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
             if (pos & 1) dst.y = v[k]; else dst.x = v[k];
         }
     }
-    // Clusters of consecutive pairs and their bounds, padded by 0.05 plus a
-    // thousandth of the cluster's diagonal.
-    // 16 triangles per cluster up to 512 clusters, 32 beyond (measured: 3 844 and 3 954 triangles are
-    // faster with 16, 16 128 and 39 600 with 32: the binning work grows with the number of clusters)
-    uint32_t cluster_pairs = n_pairs <= 512 * kClusterPairs ? kClusterPairs : 2 * kClusterPairs;
-    if (const char* env = std::getenv("RT_AMD_CLUSTER_PAIRS")) { // tuning / test knob: pairs per cluster
-        const long v = std::strtol(env, nullptr, 10);
-        if (v >= 1 && v <= 4096) cluster_pairs = (uint32_t)v;
-    }
-    while ((n_pairs + cluster_pairs - 1) / cluster_pairs > kMaxClusters) cluster_pairs *= 2;
     const uint32_t n_clusters = (uint32_t)((n_pairs + cluster_pairs - 1) / cluster_pairs);
     std::vector<float4> cl_min(n_clusters), cl_max(n_clusters);
     std::vector<uint32_t> cluster_tris(n_clusters, 0);
