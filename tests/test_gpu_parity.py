@@ -233,7 +233,7 @@ def test_other_group_sizes_give_the_same_image(group, monkeypatch):
 
 
 def test_counted_triangle_tests_and_footprint_of_a_scene_handle():
-    """Full-size headline frame: the ray-cluster pairs counted on the device give about 37 triangle tests per
+    """Full-size headline frame: the ray-cluster pairs counted on the device give about 32 triangle tests per
     path (7 175 in the exhaustive scan; 63 with the clusters in plain Morton order), and the handle's work buffers stay far below what per-cluster ray lists in global
     memory took (18 GB for this frame)."""
     import hip_mem
@@ -245,5 +245,5 @@ def test_counted_triangle_tests_and_footprint_of_a_scene_handle():
     img, st = dev.render(cam, rt.make_options(seed=1))
     used = before - hip_mem.free_bytes()
     print(f"{st.triangle_tests / st.paths:.1f} triangle tests per path, {used / 2**30:.2f} GiB held by the handle")
-    assert st.triangle_tests / st.paths == pytest.approx(36.6, rel=0.1)
+    assert st.triangle_tests / st.paths == pytest.approx(32.3, rel=0.1)
     assert used < 4 * 2**30
