@@ -269,10 +269,12 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
         } else {
             next_weight = weight * colour;
             tinted = true;
-            const float r1 = rt_rng_uniform(rng, dim);
-            const float r2 = rt_rng_uniform(rng, dim + 1);
-            dim += 2;
-            ray = random_cos(r1, r2, N);
+            if (depth + 1 < f.max_depth) { // (the last bounce casts no ray: its direction would be drawn for nothing)
+                const float r1 = rt_rng_uniform(rng, dim);
+                const float r2 = rt_rng_uniform(rng, dim + 1);
+                dim += 2;
+                ray = random_cos(r1, r2, N);
+            }
         }
     } else if (type == RT_MIRROR) {
         const V3 rr = reflect(ray, N);

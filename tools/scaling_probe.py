@@ -6,6 +6,8 @@ get (spp / N per pixel), runs the all-reduce on a one-rank RCCL group (so the
 collective's launch path and the stream overlap are exercised; the transfer
 itself is missing) and reports ms per frame.  ms(1) / ms(N) is an upper bound
 of the strong-scaling factor bench.py --gpus N can reach.
+
+    python tools/scaling_probe.py [N ...] [word ...]   # words select arrangements: serial, overlapped, two, three, four (also five, six, eight)
 """
 import gc
 import json
@@ -35,12 +37,20 @@ def main():
     dev = scene.upload()
     opt = rt.make_options(seed=1)
     out = {}
-    shares = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+    shares = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 4, 8]
+    only = [a for a in sys.argv[1:] if not a.isdigit()]  # e.g. "serial" or "three": arrangements whose label contains the word
+    words = {2: "two", 3: "three", 4: "four", 5: "five", 6: "six", 8: "eight"}
+    arrangements = [f"{words[k]} handles" for k in (4, 3, 2)] + [True, False]
+    arrangements = [f"{w} handles" for w in only if w in words.values() and f"{w} handles" not in arrangements] + arrangements
+    handles = {f"{w} handles": k for k, w in words.items()}
     for n in shares:
-        for overlapped in ("four handles", "three handles", "two handles", True, False):
+        for overlapped in arrangements:
+            name = overlapped if isinstance(overlapped, str) else ("overlapped" if overlapped else "serial")
+            if only and not any(word in name for word in only):
+                continue
             r = extra = None  # frees the previous arrangement's handles (each holds gigabytes of ray lists) before new ones are made
             gc.collect()
-            extra = [scene.upload() for _ in range({"four handles": 3, "three handles": 2, "two handles": 1}.get(overlapped, 0))]
+            extra = [scene.upload() for _ in range(handles.get(overlapped, 1) - 1)]
             r = FrameRenderer(dev, cam, opt, exchange_in_group_of_one=True, extra_devs=extra)
             r.s_begin, r.s_end = sample_range(0, n, cam.num_rays)  # rank 0's share of an n-rank run; all rows
             step = r.render_async if overlapped else r.render
