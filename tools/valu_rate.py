@@ -8,20 +8,22 @@ SIMD and prints the cycles one SIMD spends per wave-instruction.  What the
 path kernels are tuned by came out of this table:
 
   * v_fma / v_add / v_mul / v_sub _f32, v_mov, v_and / v_xor / shifts / v_add_u32
-    issue at about 2.6 cycles per wavefront once two wavefronts share the SIMD;
+    issue at about 3.0 cycles per wavefront once several wavefronts share the SIMD;
   * v_min / v_max / v_max3 / v_med3 _f32, every v_cmp, v_cndmask, every v_pk_*_f32,
     conversions, integer multiplies, v_lshl_add_u32, all f64 arithmetic and the
-    v_div_scale / v_div_fmas / v_div_fixup of an IEEE division at about 4.3,
-    and a mix of the two classes runs faster than the sum of its parts;
-  * v_sqrt / v_rcp / v_log / v_sin _f32 at about 8.2;
+    v_div_scale / v_div_fmas / v_div_fixup of an IEEE division at about 4.5-5.2,
+    and a mix of the two classes runs faster than the sum of its parts (an
+    instruction of the first class issues beside one of the second);
+  * v_sqrt / v_rcp / v_log / v_sin _f32 at about 9.2;
   * a v_cndmask_b32 in its short encoding (condition in vcc) that directly follows
-    another one stalls for about 20 cycles; the long encoding does not.
+    another one takes about 17 cycles; the long encoding does not.
 
     python tools/valu_rate.py            # writes and builds tools/valu_rate_bin (no GPU needed)
     ./tools/valu_rate_bin                # on the GPU
 
-The clock is the one the device properties report; the numbers are for comparing
-instructions with each other.
+Cycles are counted at the clock the device properties report (2.4 GHz); the
+sustained clock is lower, so the numbers are for comparing instructions with
+each other (results of one run: profiles/r02_valu_issue_rates.txt).
 """
 import os
 import subprocess
@@ -140,6 +142,8 @@ int main() {
     printf("%d CUs at %.2f GHz; cycles of one SIMD per wave-instruction with 1 2 3 4 5 8 wavefronts per SIMD\n", cus, ghz);
     float* d_out;
     CHECK(hipMalloc(&d_out, 256));
+    for (int i = 0; i < 300; i++) k_rate<0><<<cus * 8, 256>>>(d_out, 1.5f); // about a third of a second: lets the clocks settle
+    CHECK(hipDeviceSynchronize());
 '''
 
 
