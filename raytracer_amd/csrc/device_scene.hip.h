@@ -49,7 +49,7 @@ struct DeviceScene {
     const float2* tri_pair;   // 12 per PAIR of triangles (2j, 2j+1): A.x A.y A.z e1.xyz e2.xyz N.xyz,
                               // each as (value of 2j, value of 2j+1); k_mesh streams this one
     const uint32_t* tri_orig; // caller's index of the triangle at each position of tri_pair
-                              // (triangles are stored in Morton order of their centroids)
+                              // (triangles are stored in a k-d order of their centroids, see rt_scene_upload)
     const float2* cl_pair;    // padded bounds of each cluster of cluster_pairs consecutive pairs,
                               // 6 per PAIR of clusters (2k, 2k+1): lo.x lo.y lo.z hi.x hi.y hi.z
     const float2* grp_pair;   // the same for groups of group_clusters consecutive clusters (meshes of more than 64 clusters)

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
 // through the (padded) bounds of the cluster of 16 or 32 spatially adjacent
 // triangles it belongs to, before the ray's cut-off distance.  The clusters are
 // put into groups of consecutive clusters (neighbours in space, the triangles
-// being in Morton order) with the union of their bounds -- a two-level
+// being in k-d order) with the union of their bounds -- a two-level
 // bounding-volume hierarchy walked breadth first:
 //
 //   k_bin64            every queued ray against the (at most 64) group boxes

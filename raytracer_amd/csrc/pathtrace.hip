@@ -483,10 +483,11 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
         if (v >= 1 && v <= 4096) cluster_pairs = (uint32_t)v;
     }
     while ((n_pairs + cluster_pairs - 1) / cluster_pairs > kMaxClusters) cluster_pairs *= 2;
-    // Scan order of the triangle kernel: Morton order of the centroids, so
-    // that consecutive triangles are neighbours in space and a cluster of them
-    // has tight bounds.  Hits carry the caller's index (tri_orig) and ties are
-    // resolved on it, so the order does not change any result.
+    // Scan order of the triangle kernel: consecutive triangles are neighbours in
+    // space, so that a cluster of them has tight bounds -- Morton order of the
+    // centroids first (what tiny meshes and RT_AMD_ORDER=morton keep), refined
+    // into a k-d order below.  Hits carry the caller's index (tri_orig) and ties
+    // are resolved on it, so the order does not change any result.
     std::vector<uint32_t> order(d->n_triangles);
     {
         std::vector<uint64_t> keyed(d->n_triangles);
