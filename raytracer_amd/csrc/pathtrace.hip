@@ -521,7 +521,8 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     // cluster and every group of 16 consecutive clusters is a compact cell.  Clusters of
     // consecutive Morton codes straddle the curve's jumps; the cells' bounds are tighter, so a ray
     // touches fewer of them (cat mesh, headline frame: 32 instead of 63 triangle tests per path).
-    static const bool kd_order = [] { const char* e = std::getenv("RT_AMD_ORDER"); return !(e && std::strcmp(e, "morton") == 0); }(); // test knob
+    const char* order_env = std::getenv("RT_AMD_ORDER"); // test knob, read at every upload
+    const bool kd_order = !(order_env && std::strcmp(order_env, "morton") == 0);
     if (kd_order && d->n_triangles > 2 * cluster_pairs) {
         std::vector<float> cen(3 * (size_t)d->n_triangles);
         for (uint32_t i = 0; i < d->n_triangles; i++)

@@ -232,6 +232,26 @@ def test_other_group_sizes_give_the_same_image(group, monkeypatch):
     assert np.array_equal(tid, rtid) and same_bits(t, rt_)
 
 
+def test_triangle_order_changes_the_work_not_the_image(monkeypatch):
+    """The k-d order of the triangles (upload) against the plain Morton order it refines: same pixels and
+    same hits bit for bit, fewer triangle tests."""
+    s = variant("mesh_scene", "diffuse", 96, 80, 4)
+    desc, cam = s.describe()
+    opt = rt.make_options(seed=31)
+    o, d = rays_for(None, 20000, 9)
+    results = {}
+    for order in ("kd", "morton"):
+        monkeypatch.setenv("RT_AMD_ORDER", order)
+        dev = s.upload()
+        img, st = dev.render(cam, opt)
+        t, sid, tid, abg = dev.cast(rt.make_options(bounding_box=False), o, d)
+        results[order] = (img, st.triangle_tests, t, tid)
+    ref, _ = ob.render_image(desc, cam, ob.from_rt_options(opt))
+    assert same_bits(results["kd"][0], ref) and same_bits(results["morton"][0], ref)
+    assert np.array_equal(results["kd"][3], results["morton"][3]) and same_bits(results["kd"][2], results["morton"][2])
+    assert results["kd"][1] < 0.8 * results["morton"][1]
+
+
 def test_counted_triangle_tests_and_footprint_of_a_scene_handle():
     """Full-size headline frame: the ray-cluster pairs counted on the device give about 32 triangle tests per
     path (7 175 in the exhaustive scan; 63 with the clusters in plain Morton order), and the handle's work buffers stay far below what per-cluster ray lists in global
