@@ -259,6 +259,39 @@ __device__ __forceinline__ void sphere_step(float b, float n2, float R, uint32_t
     }
 }
 
+// The same step for a SHADOW ray, of which the caller uses nothing but "is any sphere hit nearer
+// than the light" (reference is_visible, src/raytrace.cu:218-244: get_distance(...) < distance to the
+// light): a sphere that certainly has no root in [0, dist] cannot change that answer and is skipped
+// without the exact square root; every other sphere takes sphere_step's arithmetic.  "Certainly":
+// v_sqrt_f32 is within one unit in the last place, so the roots computed from it are within
+// 3.1e-7 * (|b| + root of delta) of the exact code's; the band is 1e-6 * (|b| + root + dist)
+// (+ 1e-15 for a subnormal delta), and a root passes when it is below -band or above dist + band --
+// tested as |t - dist / 2| > dist / 2 + band, which is false for NaN or infinite operands (they
+// take the exact step).  With both roots outside, the exact code finds t2 < 0 (no hit), or t1 > dist,
+// or t1 < 0 and t2 > dist: never a hit nearer than the light.  On return min_dist < dist has the
+// value it has after the exact scan; min_dist and id themselves are only those of the spheres
+// that took the exact step.
+__device__ __forceinline__ void sphere_step_shadow(float b, float n2, float R, uint32_t i, float dist, float half_dist, float& min_dist,
+                                                   int& id) {
+    const float delta = b * b - n2 + R * R;
+    if (delta >= 0) {
+        const float root = __builtin_amdgcn_sqrtf(delta);
+        const float h = half_dist + (1e-6f * ((fabsf(b) + root) + dist) + 1e-15f);
+        const float t1 = -b - root, t2 = -b + root;
+        const bool out1 = fabsf(t1 - half_dist) > h, out2 = fabsf(t2 - half_dist) > h;
+        const bool clear = out1 && out2;
+        if (!clear) {
+            const float sq = sqrt_rn(delta);
+            const float e2 = -b + sq;
+            if (e2 >= 0) {
+                const float e1 = -b - sq;
+                const float t = e1 >= 0 ? e1 : e2;
+                if (id < 0 || t < min_dist) { min_dist = t; id = (int)i; }
+            }
+        }
+    }
+}
+
 // Nearest sphere along a ray (reference get_distance, src/raytrace.cu:53-87).
 __device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start, int& id) {
     float min_dist = INFINITY;
@@ -270,18 +303,34 @@ __device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, const Sce
     return min_dist;
 }
 
-// The same scan for two rays that leave the same point (a shadow ray and the
-// bounce ray of one hit): OC and its norm depend on the start only and are
-// computed once per sphere.  A ray whose flag is false keeps (inf, id).
+// The scan of a shadow ray towards a light at distance light_dist: the returned value compares with
+// light_dist (<) as nearest_sphere's does, and says nothing else (sphere_step_shadow).
+__device__ __forceinline__ float nearest_sphere_shadow(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start, float light_dist, int& id) {
+    float min_dist = INFINITY;
+    const float half = 0.5f * light_dist;
+    for_each_sphere(sc, c, [&](uint32_t i, float4 s) {
+        const V3 oc = start - xyz(s);
+        const float ocn = norm(oc);
+        sphere_step_shadow(dot(ray, oc), ocn * ocn, s.w, i, light_dist, half, min_dist, id);
+    });
+    return min_dist;
+}
+
+// One scan for two rays that leave the same point -- the shadow ray (a) towards a light at distance
+// light_dist and the bounce ray (b) of one hit: OC and its norm depend on the start only and are
+// computed once per sphere.  A ray whose flag is false keeps (inf, id); dist_a is good for the
+// comparison with light_dist only (sphere_step_shadow).
 __device__ __forceinline__ void nearest_sphere_pair(const DeviceScene& sc, const SceneCache& c, V3 start, bool do_a, V3 ray_a,
-                                                    float& dist_a, int& id_a, bool do_b, V3 ray_b, float& dist_b, int& id_b) {
+                                                    float light_dist, float& dist_a, int& id_a, bool do_b, V3 ray_b, float& dist_b,
+                                                    int& id_b) {
     dist_a = INFINITY;
     dist_b = INFINITY;
+    const float half = 0.5f * light_dist;
     for_each_sphere(sc, c, [&](uint32_t i, float4 s) {
         const V3 oc = start - xyz(s);
         const float ocn = norm(oc);
         const float n2 = ocn * ocn;
-        if (do_a) sphere_step(dot(ray_a, oc), n2, s.w, i, dist_a, id_a);
+        if (do_a) sphere_step_shadow(dot(ray_a, oc), n2, s.w, i, light_dist, half, dist_a, id_a);
         if (do_b) sphere_step(dot(ray_b, oc), n2, s.w, i, dist_b, id_b);
     });
 }

@@ -445,11 +445,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
         int shadow_sid = -1;
         bool shadow_walk = false;
         if (l == 0) {
-            nearest_sphere_pair(sc, cache, start, lit, sray, ds, shadow_sid, alive, ray, ts, sid);
+            nearest_sphere_pair(sc, cache, start, lit, sray, dist, ds, shadow_sid, alive, ray, ts, sid);
             needs_mesh_pair(sc, cache, f.bounding_box, start, lit && !(ds < dist), sray, shadow_walk, alive, ray, walk);
             bounce_probed = true;
         } else if (lit) {
-            ds = nearest_sphere(sc, cache, sray, start, shadow_sid);
+            ds = nearest_sphere_shadow(sc, cache, sray, start, dist, shadow_sid);
             shadow_walk = !(ds < dist) && needs_mesh(sc, cache, f.bounding_box, sray, start);
         }
         const size_t slot = (size_t)p * sc.n_lights + l;
@@ -647,10 +647,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
                     float ds = INFINITY;
                     int shadow_sid = -1;
                     if (l == 0) {
-                        nearest_sphere_pair(sc, cache, start, lit, sray, ds, shadow_sid, alive, ray, ts, sid);
+                        nearest_sphere_pair(sc, cache, start, lit, sray, dist, ds, shadow_sid, alive, ray, ts, sid);
                         bounce_probed = true;
                     } else if (lit) {
-                        ds = nearest_sphere(sc, cache, sray, start, shadow_sid);
+                        ds = nearest_sphere_shadow(sc, cache, sray, start, dist, shadow_sid);
                     }
                     if (lit) {
                         const bool blocked = ds < dist;
@@ -772,7 +772,18 @@ __global__ __launch_bounds__(kBlock) void k_probe_rays(DeviceScene sc, Work w, F
             w.thr[p] = make_float4(norm(target - start), 0.f, 0.f, 0.f);
         }
     }
-    launch_ray(sc, cache, w, f, 0, alive, p, start, ray);
+    if (as_segments) { // the shadow-ray scan of k_shade: its result only compares with the segment's length
+        int sid = -1;
+        float ts = INFINITY;
+        bool walk = false;
+        if (alive) {
+            ts = nearest_sphere_shadow(sc, cache, ray, start, w.thr[p].x, sid);
+            walk = needs_mesh<true>(sc, cache, f.bounding_box, ray, start);
+        }
+        commit_ray(w, 0, alive, p, start, ray, ts, sid, walk);
+    } else {
+        launch_ray(sc, cache, w, f, 0, alive, p, start, ray);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_probe_results(DeviceScene sc, Work w, Frame f, int as_segments, float* __restrict__ out_t,

@@ -58,6 +58,38 @@ def test_visible_matches_oracle(scene_name):
     assert 0 < ref.sum() < len(ref)
 
 
+@pytest.mark.parametrize("scene_name", ["default", "mesh_scene"])
+def test_visible_segments_that_end_or_start_on_a_sphere(scene_name):
+    """Shadow rays are scanned with a shortcut: a sphere whose roots are certainly outside [0, length] skips the
+    exact square root.  Segments whose end point or start point lies ON a sphere (to rounding, and a few units
+    in the last place to either side) are the cases where "certainly" must not be claimed: the verdicts have
+    to be the oracle's, which always takes the exact root."""
+    s = load(scene_name)
+    desc, cam = s.describe()
+    dev = s.upload()
+    o, d = rays_for(None, 6000, 21)
+    opt = rt.make_options()
+    t, sid, tid, _ = ob.cast(desc, ob.from_rt_options(opt), o, d)
+    on_sphere = (sid >= 0) & np.isfinite(t)
+    o, d, t = o[on_sphere], d[on_sphere], t[on_sphere]
+    assert len(o) > 3000
+    starts, targets = [], []
+    for scale in (1.0, 1.0 - 2.0 ** -23, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -21, 1.0 + 2.0 ** -21, 1.0 - 1e-6, 1.0 + 1e-6):
+        hit = (o + (np.float32(scale) * t)[:, None] * d).astype(np.float32)
+        starts.append(o)           # ends on (or a hair before / behind) the sphere it hits first
+        targets.append(hit)
+        starts.append(hit)         # starts there, towards the light and back to where it came from
+        targets.append(np.tile(np.array([[-10, 20, 40]], np.float32), (len(o), 1)))
+        starts.append(hit)
+        targets.append(o)
+    a = np.concatenate(starts).astype(np.float32)
+    b = np.concatenate(targets).astype(np.float32)
+    vis = dev.visible(opt, a, b)
+    ref = ob.visible(desc, ob.from_rt_options(opt), a, b)
+    assert np.array_equal(vis, ref)
+    assert 0.02 < ref.mean() < 0.98
+
+
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("scene_name", ["simple", "default", "mesh_scene"])
 def test_render_matches_oracle_bitwise(scene_name, mode):
