@@ -211,7 +211,8 @@ def main():
     def run(cluster_culling, steps, warmup):
         opt = rt.make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, profile=True,
                               cluster_culling=cluster_culling)
-        renderer = FrameRenderer(dev, cam, opt, want_stats=True, extra_devs=extra_devs)
+        # only rank 0's image is looked at: the sums are reduced onto it (half an all-reduce's traffic)
+        renderer = FrameRenderer(dev, cam, opt, want_stats=True, extra_devs=extra_devs, image_on_root_only=True)
         meter = Meter()
         for _ in range(warmup):
             renderer.render()

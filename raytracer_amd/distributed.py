@@ -93,7 +93,7 @@ class FrameRenderer:
     def __init__(self, dev, cam, opt, *, group=None, tensor_device="cuda",
                  accumulate: Optional[Callable] = None, resolve: Optional[Callable] = None,
                  want_stats: bool = False, depth: int = 2, exchange_in_group_of_one: bool = False,
-                 extra_devs=()):
+                 extra_devs=(), image_on_root_only: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -121,6 +121,10 @@ class FrameRenderer:
         self.side = torch.cuda.Stream() if self.overlap and not self.streams else None
         # a group of one has nothing to exchange; rehearsals of the stream logic can ask for the collective anyway
         self.exchange = self.world > 1 or (exchange_in_group_of_one and self.distributed)
+        # image_on_root_only: the sums are reduced onto the group's first rank, which alone resolves them
+        # (half the traffic of an all-reduce); the other ranks' image tensors are then not written
+        self.root_only = bool(image_on_root_only and self.distributed)
+        self.root = dist.get_global_rank(group, 0) if (self.root_only and group is not None) else 0
         self.want_stats = want_stats
         self.last_stats = None
         self._accumulate = accumulate or self._hip_accumulate
@@ -172,15 +176,24 @@ class FrameRenderer:
             self._accumulate(cam, opt, self.s_begin, self.s_end, slot.sum, (self.row_begin, self.row_end))
         if self.exchange and self.overlap:
             # the collective is ordered after the accumulate; the current stream does not wait for it
-            work = self.dist.all_reduce(slot.sum, group=self.group, async_op=True)
+            work = self._sum_over_ranks(slot.sum, async_op=True)
             with torch.cuda.stream(self.side):
                 work.wait()  # makes the side stream wait for the collective
-                self._resolve(slot.sum, slot.image)
+                self._resolve_where_wanted(slot)
                 slot.done = self.side.record_event()
         else:
             self._exchange_blocking(slot)
-            self._resolve(slot.sum, slot.image)
+            self._resolve_where_wanted(slot)
         return slot.image.view(cam.height, cam.width, 3)
+
+    def _sum_over_ranks(self, tensor, async_op=False):
+        if self.root_only:
+            return self.dist.reduce(tensor, dst=self.root, group=self.group, async_op=async_op)
+        return self.dist.all_reduce(tensor, group=self.group, async_op=async_op)
+
+    def _resolve_where_wanted(self, slot) -> None:
+        if not self.root_only or self.rank == 0:
+            self._resolve(slot.sum, slot.image)
 
     def _exchange_blocking(self, slot) -> None:
         if self.exchange:
@@ -189,7 +202,7 @@ class FrameRenderer:
             # the collective stalled for seconds.)
             if self.on_gpu:
                 self.torch.cuda.current_stream().synchronize()
-            self.dist.all_reduce(slot.sum, group=self.group)
+            self._sum_over_ranks(slot.sum)
 
     def _whole_frame_on_current_stream(self, slot, cam, opt) -> None:
         """Stream-ordered after the previous frame of this slot: same stream."""
@@ -198,10 +211,10 @@ class FrameRenderer:
             self._accumulate(cam, opt, self.s_begin, self.s_end, slot.sum, (self.row_begin, self.row_end))
         if self.exchange and self.overlap:
             # RCCL's stream waits for this one; wait() then makes this stream (only) wait for RCCL
-            self.dist.all_reduce(slot.sum, group=self.group, async_op=True).wait()
+            self._sum_over_ranks(slot.sum, async_op=True).wait()
         else:
             self._exchange_blocking(slot)
-        self._resolve(slot.sum, slot.image)
+        self._resolve_where_wanted(slot)
 
     def wait(self) -> None:
         """Orders the current stream after every frame enqueued so far."""

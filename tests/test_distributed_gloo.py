@@ -73,7 +73,7 @@ def _host_callbacks(desc, n_pixels):
     return accumulate, resolve
 
 
-def _worker(rank, world, port, spp, out_dir):
+def _worker(rank, world, port, spp, out_dir, root_only=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -84,11 +84,12 @@ def _worker(rank, world, port, spp, out_dir):
         desc, cam = s.describe()
         opt = rt.make_options(seed=21)
         acc, res = _host_callbacks(desc, cam.width * cam.height)
-        r = FrameRenderer(None, cam, opt, tensor_device="cpu", accumulate=acc, resolve=res)
+        r = FrameRenderer(None, cam, opt, tensor_device="cpu", accumulate=acc, resolve=res, image_on_root_only=root_only)
         assert (r.rank, r.world) == (rank, world)
         first = r.render().clone()
         second = r.render()  # buffers are reused: a second frame must not accumulate onto the first
-        assert torch.equal(first, second)
+        if not root_only or rank == 0:
+            assert torch.equal(first, second)
         np.save(os.path.join(out_dir, f"img{rank}.npy"), first.numpy())
         np.save(os.path.join(out_dir, f"range{rank}.npy"), np.array([r.s_begin, r.s_end]))
         np.save(os.path.join(out_dir, f"rows{rank}.npy"), np.array([r.row_begin, r.row_end]))
@@ -145,3 +146,16 @@ def test_three_ranks_two_samples_use_row_bands(tmp_path):
     assert all(np.array_equal(imgs[0], i) for i in imgs[1:])
     # every pixel's samples were added by one rank, in order: bit-identical to the single-rank frame
     assert np.array_equal(imgs[0].view(np.uint32), ref.view(np.uint32))
+
+
+def test_sums_reduced_onto_the_first_rank_only(tmp_path):
+    """image_on_root_only: a reduce instead of an all-reduce; the first rank's image is the all-reduce one's,
+    the other ranks resolve nothing."""
+    world, spp = 2, 5
+    mp.spawn(_worker, args=(world, _free_port(), spp, str(tmp_path), True), nprocs=world, join=True)
+    root = np.load(tmp_path / "img0.npy")
+    other_dir = tmp_path / "all"
+    other_dir.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), spp, str(other_dir)), nprocs=world, join=True)
+    assert np.array_equal(root.view(np.uint32), np.load(other_dir / "img0.npy").view(np.uint32))
+
