@@ -511,13 +511,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
 // renders all samples of a band of rows.  The arithmetic per bounce is k_shade's (respond_to_hit
 // and the same sphere scans), so the sums are the ones k_generate / k_shade / k_accumulate produce.
 //
-// The anti-aliasing draws of kTraceGroup samples are searched back to back, as in k_generate.
-constexpr uint32_t kTraceGroup = 4;
+// The anti-aliasing draws of a group of samples are searched back to back, as in k_generate: kTraceGroup
+// samples where a lane owns that many samples of a pixel, kTraceSearch where it owns the pixel (the longer
+// the run of searches, the closer the lanes of a wavefront finish together: 3 % of a 1 000-sample frame).
+constexpr uint32_t kTraceGroup = 4, kTraceSearch = 16;
 
 __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame f, uint32_t n_samples, float4* __restrict__ sum,
                                                           float4* __restrict__ rad, uint32_t* __restrict__ cast_count) {
     __shared__ SceneCache cache;
-    __shared__ uint32_t accepted[kTraceGroup][kBlock]; // first dimension of the accepted draw, per sample of the group
+    __shared__ uint32_t accepted[kTraceSearch][kBlock]; // first dimension of the accepted draw, per sample of the group
     __shared__ float4 eye_oc[kSphereCache];            // per cached sphere: OC = eye - centre, |OC| * |OC|
     stage_scene(sc, cache);
     if (threadIdx.x < min(sc.n_spheres, kSphereCache)) {
@@ -548,9 +550,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
     uint32_t n_casts = 0;
     const V3 eye = mk(f.pos[0], f.pos[1], f.pos[2]);
 
-    for (uint32_t s0 = s_first; s0 < s_end; s0 += kTraceGroup) {
+    const uint32_t search = buffered ? kTraceGroup : kTraceSearch;
+    for (uint32_t s0 = s_first; s0 < s_end; s0 += search) {
         if (__ballot(!done) == 0) break;
-        const uint32_t group = min(kTraceGroup, s_end - s0);
+        const uint32_t group = min(search, s_end - s0);
         if (f.antialiasing) { // the accepted draw of every sample of the group (see k_generate)
             uint32_t r = 0, dim = 0;
             rt_rng_key key = rt_rng_make_key(f.seed, pixel, f.sample_begin + s0);
