@@ -10,8 +10,13 @@ The scene is resident in HBM before the timed region; every step renders the
 whole frame in the library's default mode (cluster culling on).  With N > 1
 (one process per GPU, launched by torch.distributed.run) the 32 samples of
 every pixel are split over the ranks, each rank accumulates linear radiance for
-its sample range, the buffers are summed with one RCCL all-reduce and every
-rank resolves the image: total work is fixed (strong scaling).
+its sample range, the buffers are summed onto rank 0 with one RCCL reduce and
+rank 0 resolves the image: total work is fixed (strong scaling).
+
+Kernel durations for the roofline objects come from HIP events recorded, on the
+stream the kernels are launched on, around the kernels of three steps of the
+timed region that run alone on the device; the events are read after the
+region, so the host never waits inside it.
 
 After the timed region rank 0 also times the exhaustive-scan mode (every
 queued ray against every triangle, the reference's own amount of work) and, at
@@ -93,6 +98,17 @@ class Meter:
         self.shade_ms += st.shade_kernel_ms
         self.shade_launches += st.shade_kernel_launches
         self.casts += st.sphere_casts
+        self.frames += 1
+
+    def add_marks(self, marks, counted):
+        """A sampling step: the kernel times its marks gave, and the work a frame executes (counted once)."""
+        self.mesh_ms += marks.mesh_kernel_ms
+        self.bin_ms += marks.bin_kernel_ms
+        self.launches += marks.mesh_kernel_launches
+        self.shade_ms += marks.shade_kernel_ms
+        self.shade_launches += marks.shade_kernel_launches
+        self.tests += counted.triangle_tests
+        self.casts += counted.sphere_casts
         self.frames += 1
 
     def roofline(self, kernel, step_ms, traffic):
@@ -212,27 +228,44 @@ def main():
         opt = rt.make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, profile=True,
                               cluster_culling=cluster_culling)
         # only rank 0's image is looked at: the sums are reduced onto it (half an all-reduce's traffic)
+        # the marks of a sampling step are recorded on the stream and read after the region (profile = 2)
+        opt_marks = rt.make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, profile=2,
+                                    cluster_culling=cluster_culling)
         renderer = FrameRenderer(dev, cam, opt, want_stats=True, extra_devs=extra_devs, image_on_root_only=True)
         meter = Meter()
         for _ in range(warmup):
             renderer.render()
+        # what a frame executes (rays cast, triangle tests): every step renders the same frame, so the counters are
+        # read once, here, outside the timed region
+        counted = renderer.last_stats
+        if counted is None:
+            renderer.render()
+            counted = renderer.last_stats
+        renderer.want_stats = False
         fence()
+        pending = []  # scene handles with marks to read
         t0 = time.perf_counter()
         for i in range(steps):
             # Steps just enqueue: consecutive frames overlap on the device (a stream per frame in flight), and with
-            # N > 1 so do the all-reduce of one frame and the kernels of the next.  Three steps of the
-            # region (at its start, one third and two thirds) are sampling steps: the device is drained first,
-            # so that the frame runs alone and the HIP events around its kernels time them undisturbed; its
-            # counters are read back.
-            sampling = i in (0, steps // 3, (2 * steps) // 3)
+            # N > 1 so do the exchange of one frame and the kernels of the next.  Three steps of the region (its
+            # first, its middle and its last one) are sampling steps: the frame runs ALONE on the device -- its stream
+            # waits for the frames in flight, the later frames' streams wait for it -- with HIP events recorded around
+            # its kernels on the stream they are launched on.  The host waits for nothing: the events are read after
+            # the region.  (The first and the last step are where the device is empty, or has to drain, anyway.)
+            sampling = i in (0, steps // 2, steps - 1)
             if sampling:
-                torch.cuda.synchronize()
-            renderer.want_stats = sampling
-            renderer.last_stats = None
-            renderer.render_async()
-            meter.add(renderer.last_stats)
+                handle = renderer.devs[renderer.frame % len(renderer.devs)] if renderer.streams else renderer.dev
+                if handle in pending:  # its earlier sampling step finished long ago: reading its marks waits for nothing
+                    meter.add_marks(handle.profile_collect(), counted)
+                    pending.remove(handle)
+                renderer.render_async(opt=opt_marks, alone=True)
+                pending.append(renderer.last_dev)
+            else:
+                renderer.render_async()
         fence()
         elapsed = time.perf_counter() - t0
+        for handle in pending:
+            meter.add_marks(handle.profile_collect(), counted)
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -290,7 +323,7 @@ def main():
                 "workload": f"{args.scene}.json {cam.width}x{cam.height} {spp}spp depth5 indirect+AA+bbox",
                 "triangles": int(desc.n_triangles),
                 "mode": "cluster culling on (library default; image bit-identical to the exhaustive scan)",
-                "parallelism": f"spp-split x{world} + RCCL all-reduce of linear radiance" if world > 1 else "single GPU",
+                "parallelism": f"spp-split x{world} + RCCL reduce of linear radiance onto rank 0" if world > 1 else "single GPU",
                 "frames_in_flight": max(args.frames_in_flight, 1),
             },
         }

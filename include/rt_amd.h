@@ -81,7 +81,9 @@ typedef struct rt_options {
     int32_t bounding_box;
     int32_t max_depth; /* 5 in the reference */
     uint32_t seed;
-    int32_t profile;   /* non-zero: time the triangle kernel with events */
+    int32_t profile;   /* 1: kernel timings in the call's rt_stats (the call then waits for its work);
+                          2, with stats == NULL: timing marks are recorded on the stream and nothing
+                          is read -- rt_profile_collect fetches them later */
     /* 0: every queued ray is tested against every triangle, the reference's
      * scan (src/raytrace.cu:148-175), and every path runs all its bounces.
      * Non-zero: triangles are grouped into clusters of 16 or 32 neighbours and a ray
@@ -158,6 +160,15 @@ int rt_resolve(const float* d_sum, uint32_t n_pixels, float* d_out_rgb, void* st
 int rt_accumulate_rows(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
                        uint32_t sample_begin, uint32_t sample_end, uint32_t row_begin,
                        uint32_t row_end, float* d_sum, void* stream, rt_stats* stats);
+
+/* The kernel timings of the last rt_accumulate / rt_accumulate_rows call made
+ * on this handle with rt_options.profile = 2 and stats == NULL (the reference
+ * times its one kernel with events around the launch, src/raytrace.cu:572-633,
+ * and waits for it; a call of that kind only records its marks on the stream,
+ * so the host goes on queueing work): waits for that call's work and fills
+ * gpu_ms and the *_kernel_ms / *_launches fields, the rest is zero.
+ * RT_ERR_INVALID when no such call is outstanding. */
+int rt_profile_collect(rt_scene* scene, rt_stats* stats);
 
 /* d_dst[i] += d_src[i] for n_floats floats of DEVICE memory on the current
  * device (16-byte aligned buffers): adds the sums another device produced,

@@ -178,7 +178,7 @@ EXPORTS = [
     "rt_host_scene_set_options", "rt_host_scene_render", "rt_host_scene_describe", "rt_host_scene_image",
     "rt_write_png", "rt_write_pfm", "rt_set_progress", "rt_host_scene_render_frames", "rt_accumulate_rows",
     "rt_accumulate_static", "rt_add_sums", "rt_frame_partition", "rt_device_group_create", "rt_device_group_render",
-    "rt_device_group_free", "rt_host_scene_set_devices", "rt_random_cos",
+    "rt_device_group_free", "rt_host_scene_set_devices", "rt_random_cos", "rt_profile_collect",
 ]
 
 
@@ -290,6 +290,13 @@ class DeviceScene:
         row_begin, row_end = rows if rows is not None else (0, cam.height)
         _check(lib.rt_accumulate_rows(self._h, C.byref(cam), C.byref(opt), sample_begin, sample_end, row_begin, row_end,
                                       C.c_void_p(d_sum_ptr), C.c_void_p(stream), C.byref(st) if st is not None else None))
+        return st
+
+    def profile_collect(self) -> Stats:
+        """The kernel timings of the last accumulate() made with make_options(profile=2) and want_stats=False:
+        that call only recorded its marks on the stream; this one waits for its work and reads them."""
+        st = Stats()
+        _check(lib.rt_profile_collect(self._h, C.byref(st)))
         return st
 
     def accumulate_static(self, cam: Camera, opt: Options, sample_begin: int, sample_end: int, d_sum_ptr: int,

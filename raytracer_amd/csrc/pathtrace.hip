@@ -94,6 +94,7 @@ struct rt_scene {
     std::vector<hipEvent_t> events;   // pool, reused by every call
     std::vector<char> event_tags;     // tag of the events in use, in record order
     hipEvent_t frame_begin = nullptr, frame_end = nullptr;
+    bool marks_pending = false;       // a call with rt_options.profile == 2 left timing marks for rt_profile_collect
     // rt_render's device buffers (sums and output image), grown on demand
     float* frame_sum = nullptr;
     float* frame_out = nullptr;
@@ -723,6 +724,30 @@ BatchShape batch_shape(uint32_t width, uint32_t rows, uint32_t n_samples, uint32
     return b;
 }
 
+// Waits for the frame-end mark and turns the marks of the call into times: the whole call, and per kind of
+// kernel ('B' binning starts, 'M' triangle kernel starts, 'S' k_shade starts, 'E' it ended).
+int read_marks(rt_scene* s, rt_stats* stats) {
+    HIP_TRY(hipEventSynchronize(s->frame_end));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->frame_begin, s->frame_end));
+    stats->gpu_ms = ms;
+    for (size_t i = 0; i + 1 < s->event_tags.size(); i++) {
+        if (s->event_tags[i] == 'E') continue;
+        float k = 0.f;
+        HIP_TRY(hipEventElapsedTime(&k, s->events[i], s->events[i + 1]));
+        if (s->event_tags[i] == 'B') {
+            stats->bin_kernel_ms += k;
+        } else if (s->event_tags[i] == 'S') {
+            stats->shade_kernel_ms += k;
+            stats->shade_kernel_launches++;
+        } else {
+            stats->mesh_kernel_ms += k;
+            stats->mesh_kernel_launches++;
+        }
+    }
+    return RT_OK;
+}
+
 // The body of rt_accumulate_rows on a given set of work buffers, which must hold batches of
 // shape.rows_per_chunk * width * shape.per_batch paths with max_depth + 1 triangle stages.
 // With stats == nullptr and no progress callback it only enqueues work and allocates nothing.
@@ -737,15 +762,19 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
     const uint32_t n_counters = (uint32_t)opt->max_depth + 1u;
     const uint64_t total_paths = (uint64_t)n_samples * (row_end - row_begin) * cam->width;
 
-    const bool profile = stats && opt->profile;
+    // profile == 2 without statistics: the timing marks are recorded on the stream and read later (rt_profile_collect),
+    // so that the call neither waits for the device nor keeps the host from queueing the next frame
+    const bool deferred = !stats && opt->profile == 2;
+    const bool profile = (stats && opt->profile) || deferred;
     f.count_casts = stats != nullptr;
     const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
     f.prune_zero_terms = opt->cluster_culling != 0;
     const size_t cl_words = cull && stats ? (size_t)n_counters * ws.tiles * s->d.n_clusters * kCountStride : 0;
     std::vector<uint32_t> cl_counts(cl_words);
     uint64_t tests = 0;
-    s->event_tags.clear();
-    if (stats) {
+    if (stats || deferred) { // (a call without marks leaves those of an earlier call alone)
+        s->event_tags.clear();
+        s->marks_pending = false;
         if (!s->frame_begin) HIP_TRY(hipEventCreate(&s->frame_begin));
         if (!s->frame_end) HIP_TRY(hipEventCreate(&s->frame_end));
         HIP_TRY(hipEventRecord(s->frame_begin, stream));
@@ -818,26 +847,13 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             }
         }
     }
+    if (deferred) {
+        HIP_TRY(hipEventRecord(s->frame_end, stream));
+        s->marks_pending = true;
+    }
     if (stats) {
         HIP_TRY(hipEventRecord(s->frame_end, stream));
-        HIP_TRY(hipEventSynchronize(s->frame_end));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, s->frame_begin, s->frame_end));
-        stats->gpu_ms = ms;
-        for (size_t i = 0; i + 1 < s->event_tags.size(); i++) {
-            if (s->event_tags[i] == 'E') continue;
-            float k = 0.f;
-            HIP_TRY(hipEventElapsedTime(&k, s->events[i], s->events[i + 1]));
-            if (s->event_tags[i] == 'B') {
-                stats->bin_kernel_ms += k;
-            } else if (s->event_tags[i] == 'S') {
-                stats->shade_kernel_ms += k;
-                stats->shade_kernel_launches++;
-            } else {
-                stats->mesh_kernel_ms += k;
-                stats->mesh_kernel_launches++;
-            }
-        }
+        if ((rc = read_marks(s, stats)) != RT_OK) return rc;
         stats->batches = batches;
         stats->paths = paths;
         stats->mesh_rays = mesh_rays;
@@ -1034,6 +1050,14 @@ extern "C" int rt_add_sums(float* d_dst, const float* d_src, uint32_t n_floats, 
                        d_src + 4 * (size_t)n_vec4, n_tail);
     HIP_TRY(hipGetLastError());
     return RT_OK;
+}
+
+extern "C" int rt_profile_collect(rt_scene* s, rt_stats* stats) {
+    if (!s || !stats) { rt_set_error("rt_profile_collect: null argument"); return RT_ERR_INVALID; }
+    if (!s->marks_pending) { rt_set_error("rt_profile_collect: no call with rt_options.profile = 2 left marks on this handle"); return RT_ERR_INVALID; }
+    std::memset(stats, 0, sizeof *stats);
+    s->marks_pending = false;
+    return read_marks(s, stats);
 }
 
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* opt, float* out_rgb, rt_stats* stats) {

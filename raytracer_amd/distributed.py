@@ -130,6 +130,7 @@ class FrameRenderer:
         self._accumulate = accumulate or self._hip_accumulate
         self._resolve = resolve or self._hip_resolve
         self._active_dev = dev
+        self.last_dev = dev  # the scene handle the most recent frame was rendered with
 
     # the buffers of the most recent frame (kept for callers that look at them)
     @property
@@ -152,8 +153,12 @@ class FrameRenderer:
 
         rt.resolve(sum_tensor.data_ptr(), self.n_pixels, out_tensor.data_ptr(), self._stream())
 
-    def render_async(self, cam=None, opt=None):
-        """Enqueues one frame; returns its (H, W, 3) image tensor, valid after wait()."""
+    def render_async(self, cam=None, opt=None, alone=False):
+        """Enqueues one frame; returns its (H, W, 3) image tensor, valid after wait().
+
+        alone (several handles only): the frame runs with nothing beside it on the device -- its stream waits for
+        the frames in flight, the streams of the later frames wait for it -- without the host waiting for anything.
+        For timing a frame's kernels undisturbed (opt with profile = 2, then last_dev.profile_collect())."""
         torch = self.torch
         cam = cam if cam is not None else self.cam
         opt = opt if opt is not None else self.opt
@@ -163,11 +168,17 @@ class FrameRenderer:
         if self.streams:
             stream = self.streams[k]
             stream.wait_stream(torch.cuda.current_stream())  # after whatever the caller queued before
-            self._active_dev = self.devs[k]
+            others = [x for x in self.streams if x is not stream] if alone else []
+            for other in others:
+                stream.wait_stream(other)
+            self._active_dev = self.last_dev = self.devs[k]
             with torch.cuda.stream(stream):
                 self._whole_frame_on_current_stream(slot, cam, opt)
             self._active_dev = self.dev
+            for other in others:
+                other.wait_stream(stream)
             return slot.image.view(cam.height, cam.width, 3)
+        self.last_dev = self.dev
         if slot.done is not None:  # the frame that used these buffers `depth` frames ago
             torch.cuda.current_stream().wait_event(slot.done)
             slot.done = None

@@ -633,3 +633,34 @@ def test_pipelined_frames_over_rccl_group_of_one(tmp_path, mode):
         port = sock.getsockname()[1]
     mp.start_processes(_pipelined_worker, args=(1, port, str(tmp_path), mode), nprocs=1, join=True, start_method="spawn")
     assert os.path.exists(tmp_path / f"ok_{mode.replace(' ', '_')}.npy")
+
+
+def test_timing_marks_collected_after_the_call():
+    """rt_options.profile = 2: the call records its marks on the stream and returns; rt_profile_collect reads the
+    kernel times later.  They cover the same launches as the blocking statistics of profile = 1."""
+    import hip_mem
+
+    s = load("mesh_scene", 128, 96, 4)
+    desc, cam = s.describe()
+    dev = s.upload()
+    n = cam.width * cam.height
+    with pytest.raises(rt.RtError):
+        dev.profile_collect()  # nothing outstanding
+    sums = hip_mem.DeviceBuffer(n * 4)
+    sums.zero()
+    blocking = dev.accumulate(cam, rt.make_options(seed=3, profile=1), 0, 4, sums.address, want_stats=True)
+    first = sums.to_host().copy()
+    sums.zero()
+    assert dev.accumulate(cam, rt.make_options(seed=3, profile=2), 0, 4, sums.address) is None
+    other = hip_mem.DeviceBuffer(n * 4)
+    dev.accumulate(cam, rt.make_options(seed=3), 0, 1, other.address)  # a call without marks leaves them alone
+    marks = dev.profile_collect()
+    assert np.array_equal(sums.to_host().view(np.uint32), first.view(np.uint32))
+    assert marks.shade_kernel_launches == blocking.shade_kernel_launches == 5
+    assert marks.mesh_kernel_launches == blocking.mesh_kernel_launches == 6
+    assert marks.gpu_ms > 0 and marks.shade_kernel_ms > 0 and marks.mesh_kernel_ms > 0 and marks.bin_kernel_ms > 0
+    assert marks.shade_kernel_ms + marks.mesh_kernel_ms + marks.bin_kernel_ms <= marks.gpu_ms
+    assert marks.paths == 0 and marks.triangle_tests == 0  # timings only
+    with pytest.raises(rt.RtError):
+        dev.profile_collect()  # already collected
+
