@@ -258,7 +258,10 @@ def main():
                 if handle in pending:  # its earlier sampling step finished long ago: reading its marks waits for nothing
                     meter.add_marks(handle.profile_collect(), counted)
                     pending.remove(handle)
-                renderer.render_async(opt=opt_marks, alone=True)
+                # (with N > 1 a rank's share of a frame is a sixth of a millisecond of work in thirty kernels, and a frame
+                # that runs alone costs more than the step itself: there the sampled frames stay in flight beside the
+                # others and their kernels' durations are stretched by what runs next to them)
+                renderer.render_async(opt=opt_marks, alone=world == 1)
                 pending.append(renderer.last_dev)
             else:
                 renderer.render_async()
@@ -340,6 +343,10 @@ def main():
         else:
             line["roofline"], line["roofline_k_shade"] = mesh, shade
         line["roofline_whole_step"] = meter.frame_roofline(ms_per_step, int(desc.n_spheres), int(desc.n_boxes), world)
+        line["kernel_durations"] = ("HIP events on the launch stream around the kernels of three steps of the timed region "
+                                    + ("that ran alone on the device" if world == 1 else
+                                       "in flight beside the other frames (stretched by what ran next to them)")
+                                    + ", read after the region")
         if exhaustive is not None:
             ex_elapsed, ex_meter, ex_steps = exhaustive
             line["exhaustive_scan"] = {
