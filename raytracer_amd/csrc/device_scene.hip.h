@@ -23,7 +23,9 @@ constexpr uint32_t kCastShards = 1024;      // statistics counters per path kern
 constexpr uint64_t kNoHit = 0x7f800000ffffffffULL; // (t = +inf, triangle = none)
 constexpr uint32_t kMaxPathsPerBatch = 1u << 24;
 constexpr uint32_t kMaxLights = 64;
-constexpr uint32_t kClusterPairs = 8;       // triangle pairs per culling cluster of a small mesh (16 triangles; swept 4-32 on the cat mesh)
+constexpr uint32_t kClusterPairs = 8;       // triangle pairs per culling cluster of a small mesh (16 triangles; 8 triangles are 2 % faster on the cat
+                                            // mesh in k-d order, but twice the groups double the provision for the per-group ray lists: +1.1 GB)
+constexpr uint32_t kFusedClusterPairsMax = 100; // clusters grow with the mesh up to this size to stay within k_group_clusters' 1 024 clusters
 constexpr uint32_t kMaxClusters = 64 * 64;  // two levels of at most 64 boxes each; larger meshes get larger clusters
 constexpr uint32_t kFusedGroup = 16;        // clusters per group at most where k_group_clusters is used ...
 constexpr uint32_t kFusedMaxGroups = 64;    // ... which is for meshes of up to 64 such groups

@@ -476,9 +476,14 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     const size_t n_pairs = ((size_t)d->n_triangles + 1) / 2;
     // Clusters of consecutive pairs and their bounds, padded by 0.05 plus a
     // thousandth of the cluster's diagonal.
-    // 16 triangles per cluster up to 512 clusters, 32 beyond (measured: 3 844 and 3 954 triangles are
-    // faster with 16, 16 128 and 39 600 with 32: the binning work grows with the number of clusters)
-    uint32_t cluster_pairs = n_pairs <= 512 * kClusterPairs ? kClusterPairs : 2 * kClusterPairs;
+    // Cluster size: as many clusters as k_group_clusters takes (64 groups of 16), of at least 16 triangles -- up to
+    // about 200 000 triangles the kernel that keeps the second level in LDS beats the one with per-cluster lists
+    // in global memory even though its clusters grow with the mesh (measured on meshes of 3 844 to 638 400
+    // triangles in k-d order, against clusters of 32 triangles and the global lists: 16 triangles per cluster at
+    // 16 128: -4 %, 40 at 39 600: -21 %, 78 at 77 840: -39 %, 156 at 159 200: -27 %; 312 at 319 224: equal;
+    // 624 at 638 400: +32 %).  Larger meshes get clusters of 32 triangles or more and the global lists.
+    uint32_t cluster_pairs = std::max<uint32_t>(kClusterPairs, (uint32_t)((n_pairs + kFusedMaxGroups * kFusedGroup - 1) / (kFusedMaxGroups * kFusedGroup)));
+    if (cluster_pairs > kFusedClusterPairsMax) cluster_pairs = 16;
     if (const char* env = std::getenv("RT_AMD_CLUSTER_PAIRS")) { // tuning / test knob: pairs per cluster
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 1 && v <= 4096) cluster_pairs = (uint32_t)v;
