@@ -166,7 +166,8 @@ int rt_accumulate_rows(rt_scene* scene, const rt_camera* cam, const rt_options* 
  * times its one kernel with events around the launch, src/raytrace.cu:572-633,
  * and waits for it; a call of that kind only records its marks on the stream,
  * so the host goes on queueing work): waits for that call's work and fills
- * gpu_ms and the *_kernel_ms / *_launches fields, the rest is zero.
+ * gpu_ms and the *_kernel_ms / *_launches fields, the rest is zero (a scene
+ * without triangles is traced by one kernel: only gpu_ms is filled).
  * RT_ERR_INVALID when no such call is outstanding. */
 int rt_profile_collect(rt_scene* scene, rt_stats* stats);
 

@@ -885,10 +885,13 @@ int accumulate_spheres(rt_scene* s, const rt_camera* cam, const rt_options* opt,
     f.prune_zero_terms = opt->cluster_culling != 0;
     const uint32_t n_samples = sample_end - sample_begin;
     const uint64_t total_paths = (uint64_t)n_samples * (row_end - row_begin) * cam->width;
-    if (stats) {
+    const bool deferred = !stats && opt->profile == 2; // marks for rt_profile_collect: here only the whole call is timed
+    if (stats || deferred) {
+        s->event_tags.clear();
+        s->marks_pending = false;
         if (!s->frame_begin) HIP_TRY(hipEventCreate(&s->frame_begin));
         if (!s->frame_end) HIP_TRY(hipEventCreate(&s->frame_end));
-        HIP_TRY(hipMemsetAsync(cast_count, 0, (size_t)kCastShards * kCountStride * sizeof(uint32_t), stream));
+        if (stats) HIP_TRY(hipMemsetAsync(cast_count, 0, (size_t)kCastShards * kCountStride * sizeof(uint32_t), stream));
         HIP_TRY(hipEventRecord(s->frame_begin, stream));
     }
     uint64_t paths = 0;
@@ -935,6 +938,10 @@ int accumulate_spheres(rt_scene* s, const rt_camera* cam, const rt_options* opt,
                                reinterpret_cast<float4*>(d_sum));
             if ((rc = after_launch(f.n_paths)) != RT_OK) return rc;
         }
+    }
+    if (deferred) {
+        HIP_TRY(hipEventRecord(s->frame_end, stream));
+        s->marks_pending = true;
     }
     if (stats) {
         HIP_TRY(hipEventRecord(s->frame_end, stream));

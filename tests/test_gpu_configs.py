@@ -663,4 +663,11 @@ def test_timing_marks_collected_after_the_call():
     assert marks.paths == 0 and marks.triangle_tests == 0  # timings only
     with pytest.raises(rt.RtError):
         dev.profile_collect()  # already collected
+    # a scene without triangles is one kernel: only the whole call is timed
+    spheres = load("default", 128, 96, 4)
+    _, scam = spheres.describe()
+    sdev = spheres.upload()
+    sdev.accumulate(scam, rt.make_options(seed=3, profile=2), 0, 4, sums.address)
+    smarks = sdev.profile_collect()
+    assert smarks.gpu_ms > 0 and smarks.shade_kernel_launches == 0 and smarks.mesh_kernel_launches == 0
 
