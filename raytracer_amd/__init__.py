@@ -16,7 +16,8 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIB: another build of the library (tuning experiments: tools/build_variant.sh)
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 REPO_ROOT = os.path.dirname(_HERE)
 ASSETS = os.path.join(REPO_ROOT, "assets")
 

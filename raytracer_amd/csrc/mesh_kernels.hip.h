@@ -134,6 +134,62 @@ __device__ __forceinline__ void test_pair(const PairData& p, const uint32_t* __r
     }
 }
 
+// test_pair for a lane that meets this (ray, pair) once and reports every hit it finds instead of
+// keeping the nearest: emit(h, numerator, denominator) is called for triangle h of the pair when the
+// reference's test (src/raytrace.cu:161-174) accepts it with a distance t = numerator / denominator in
+// (0, cutoff).  The caller merges hits of one ray with the atomic minimum on (t, caller's triangle index),
+// which is the reference's "nearest, first triangle wins ties" whatever the order of arrival.  Same
+// division-free filter and the same exact tail as test_pair / candidate; `live` = false masks the lane.
+template <typename Emit>
+__device__ __forceinline__ void pair_hits(const PairData& p, bool live, float ox, float oy, float oz, float ux, float uy, float uz,
+                                          float cutoff, Emit&& emit) {
+    const f2 Ax = p.v[0], Ay = p.v[1], Az = p.v[2];
+    const f2 e1x = p.v[3], e1y = p.v[4], e1z = p.v[5];
+    const f2 e2x = p.v[6], e2y = p.v[7], e2z = p.v[8];
+    const f2 Nx = p.v[9], Ny = p.v[10], Nz = p.v[11];
+    const f2 aox = Ax - ox, aoy = Ay - oy, aoz = Az - oz;
+    const f2 qx = aoy * uz - aoz * uy;
+    const f2 qy = aoz * ux - aox * uz;
+    const f2 qz = aox * uy - aoy * ux;
+    const f2 d = (ux * Nx + uy * Ny) + uz * Nz;
+    const f2 nb = (e2x * qx + e2y * qy) + e2z * qz; // e2 . q
+    const f2 ng = (e1x * qx + e1y * qy) + e1z * qz; // e1 . q
+    f2 rcp;
+    rcp.x = __builtin_amdgcn_rcpf(d.x);
+    rcp.y = __builtin_amdgcn_rcpf(d.y);
+    const f2 b_ = nb * rcp;
+    const f2 g_ = -ng * rcp;
+    const f2 a_ = (1.f - b_) - g_;
+    const float lo0 = fminf(fminf(a_.x, b_.x), g_.x);
+    const float lo1 = fminf(fminf(a_.y, b_.y), g_.y);
+    const bool c0 = live && !(lo0 < -1e-5f), c1 = live && !(lo1 < -1e-5f);
+    if (c0 || c1) {
+        const f2 aon = (aox * Nx + aoy * Ny) + aoz * Nz;
+        auto one = [&](int h, float lo, float nb_, float ng_, float d_, float rcp_, float aon_) {
+            bool inside = lo >= 1e-5f; // the exact barycentrics are certainly positive
+            if (!inside) {             // near an edge (or NaN): the reference's own quotients decide
+                const float beta = nb_ / d_;
+                const float gamma = -ng_ / d_;
+                const float alpha = 1.f - beta - gamma;
+                inside = alpha >= 0 && beta >= 0 && gamma >= 0;
+            }
+            if (inside) {
+                // the approximate distance is within 3e-7 (relative) of the exact quotient: a factor 1 + 2e-6
+                // decides 0 < t < cutoff without a division, anything closer (or NaN) is decided exactly
+                const float t_ = aon_ * rcp_;
+                bool valid = t_ * 1.000002f < cutoff && t_ > 1e-30f;
+                if (!valid && !(t_ > cutoff * 1.000002f || t_ < 0.f)) {
+                    const float t = aon_ / d_;
+                    valid = t > 0 && t < cutoff;
+                }
+                if (valid) emit(h, aon_, d_);
+            }
+        };
+        if (c0) one(0, lo0, nb.x, ng.x, d.x, rcp.x, aon.x);
+        if (c1) one(1, lo1, nb.y, ng.y, d.y, rcp.y, aon.y);
+    }
+}
+
 // Lane l of every wavefront holds shard l's ray count and the number of
 // 256-ray blocks in the shards before it.
 struct ShardMap {
@@ -332,8 +388,8 @@ __device__ __forceinline__ SlabRay slab_ray(float4 o4, float4 d4) {
 }
 
 // Slab tests of R rays per lane against box pairs [first, last), last - first
-// <= 16: bit 2(k - first) + h of bits[i] is set when ray i enters box h of
-// pair k before its cut-off distance.  The slab parameters come from packed
+// <= 16: bit 2(k - first) + h of bits[i] is set when ray i is inside box h of
+// pair k somewhere between its start and its cut-off distance.  The slab parameters come from packed
 // FMAs (t = bound * (1/u) - origin * (1/u)); this is only a filter and need not
 // follow the reference's rounding.  NaN parameters (the axes slab_ray took out
 // of the test, or 0 * inf) are dropped by the minimum / maximum: that axis does
@@ -347,22 +403,28 @@ __device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint3
     for (uint32_t k = first; k < last; k++) {
         const f2* __restrict__ b = box_pair + 6 * (size_t)k;
         const f2 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
-        const uint32_t bit = 1u << (2 * (k - first)); // wave-uniform
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const SlabRay& r = ray[i];
             const f2 ax = __builtin_elementwise_fma(b0, (f2)(r.ix), (f2)(-r.ox)), bx = __builtin_elementwise_fma(b3, (f2)(r.ix), (f2)(-r.ox));
             const f2 ay = __builtin_elementwise_fma(b1, (f2)(r.iy), (f2)(-r.oy)), by = __builtin_elementwise_fma(b4, (f2)(r.iy), (f2)(-r.oy));
             const f2 az = __builtin_elementwise_fma(b2, (f2)(r.iz), (f2)(-r.oz)), bz = __builtin_elementwise_fma(b5, (f2)(r.iz), (f2)(-r.oz));
-            const float in0 = hw_max3(hw_min(ax.x, bx.x), hw_min(ay.x, by.x), hw_min(az.x, bz.x));
-            const float out0 = hw_min3(hw_max(ax.x, bx.x), hw_max(ay.x, by.x), hw_max(az.x, bz.x));
-            const float in1 = hw_max3(hw_min(ax.y, bx.y), hw_min(ay.y, by.y), hw_min(az.y, bz.y));
-            const float out1 = hw_min3(hw_max(ax.y, bx.y), hw_max(ay.y, by.y), hw_max(az.y, bz.y));
-            const bool t0 = (out0 >= hw_max(in0, 0.f)) & (in0 <= r.cutoff);
-            const bool t1 = (out1 >= hw_max(in1, 0.f)) & (in1 <= r.cutoff);
-            bits[i] |= (t0 ? bit : 0u) | (t1 ? bit << 1 : 0u);
+            // entry, not before the ray's start; exit, not beyond its cut-off distance; the ray touches the box when
+            // the interval is not empty.  The verdicts are shifted into bits[i] through the carry: the first box
+            // tested ends up in the highest of the bits used.
+            const float in0 = hw_max3(hw_min(ax.x, bx.x), hw_min(ay.x, by.x), hw_max(hw_min(az.x, bz.x), 0.f));
+            const float out0 = hw_min3(hw_max(ax.x, bx.x), hw_max(ay.x, by.x), hw_min(hw_max(az.x, bz.x), r.cutoff));
+            const float in1 = hw_max3(hw_min(ax.y, bx.y), hw_min(ay.y, by.y), hw_max(hw_min(az.y, bz.y), 0.f));
+            const float out1 = hw_min3(hw_max(ax.y, bx.y), hw_max(ay.y, by.y), hw_min(hw_max(az.y, bz.y), r.cutoff));
+            asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                "v_cmp_ge_f32 vcc, %3, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                : "+v"(bits[i]) : "v"(out0), "v"(in0), "v"(out1), "v"(in1) : "vcc");
         }
     }
+    // box 2 (k - first) + h to bit 2 (k - first) + h
+    const uint32_t used = 2 * (last - first);
+#pragma unroll
+    for (int i = 0; i < R; i++) bits[i] = used ? __brev(bits[i]) >> (32 - used) : 0u;
 }
 
 // The boxes (up to 64, as a bit mask) that S rays per lane enter before their
@@ -498,19 +560,46 @@ __global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl
 // ---- second level and triangle scan in one kernel ---------------------------
 //
 // For meshes of up to kFusedMaxGroups * kFusedGroup clusters the groups hold at most kFusedGroup
-// clusters each, and the rays on a group's list are binned into that group's clusters IN LDS and
-// scanned against the clusters' triangles by the same workgroup: no per-cluster lists in global
-// memory (they were the bulk of a scene handle's footprint), no global reservations, no job table,
-// and one kernel less per triangle stage.
+// clusters each, and the rays on a group's list are binned into that group's clusters and scanned
+// against the clusters' triangles by the same workgroup, through LDS: no per-cluster lists in
+// global memory, no global reservations, no job table, one kernel less per triangle stage.
 //
 // A workgroup of T threads takes a contiguous run of one group's list (a few passes of R * T
-// entries).  Per pass: every lane tests its entries' rays against the group's cluster boxes and
-// appends, per touched cluster, a 16-bit reference to the ray into that cluster's LDS list; then
-// the wavefronts take (cluster, 64 references) jobs -- the pair scan of k_mesh over the cluster's
-// triangle pairs -- as long as full jobs are left.  What remains of a list (fewer than 64
-// references) is carried into the next pass, so the lanes of a job are all busy except in the run's
-// last pass, which scans the partial jobs too.
-template <int R, int T>
+// entries).  A pass has two phases:
+//
+//   bin    every lane fetches its entries' rays, keeps them in LDS (32 bytes each) and tests them
+//          against the group's cluster boxes: a 16-bit mask per entry, also in LDS;
+//   scan   the wavefronts draw (cluster, half of the pass) units from a counter.  A unit's entries
+//          are compacted into the wavefront's own list, and the wavefront then works as 8 triangle
+//          pairs x 8 rays: a lane keeps ONE pair of the cluster in registers for the whole unit
+//          (clusters of more than 8 pairs: one chunk of 8 after the other) and meets a new ray, read
+//          from LDS, every trip -- 128 ray-triangle tests per trip, the packed arithmetic of k_mesh.
+//
+// Compared with a lane per ray and a wave-uniform triangle (k_mesh, where thousands of rays share
+// one long triangle stream): no chain of dependent scalar loads per unit (a cluster is 8 steps
+// long, and the three workgroups of a CU walk different groups, which defeats the scalar cache),
+// rays come in eights instead of sixty-fours, so a unit of 37 rays wastes 3 slots instead of 27 and
+// nothing has to be carried from pass to pass, and the rays are read from memory once per pass.
+//
+// A lane's hit is final for that (ray, pair): it goes to the ray's slot with the 64-bit atomic
+// minimum on (t bits, caller's triangle index) that merges chunks and clusters anyway.  The exact
+// quotient of an accepted hit is deferred (`pend`): a lane flushes it when its next hit arrives
+// or the pass ends, so the division and the atomic run about once per pass, not once per trip.
+struct PendingHit {
+    float num, den;
+    uint32_t orig;   // caller's index of the triangle; 0xffffffff: none pending
+    uint32_t slot;
+};
+
+__device__ __forceinline__ void flush_hit(PendingHit& pend, unsigned long long* __restrict__ hit) {
+    if (pend.orig != 0xffffffffu) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(pend.num / pend.den) << 32) | pend.orig;
+        atomicMin(&hit[pend.slot], key);
+        pend.orig = 0xffffffffu;
+    }
+}
+
+template <int R, int T, int U>
 __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
                                                       uint32_t n_clusters, uint32_t cluster_pairs, uint32_t n_groups,
                                                       uint32_t group_clusters, const f2* __restrict__ cl_pair,
@@ -520,13 +609,13 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
                                                       uint32_t* __restrict__ cl_stat) {
     constexpr uint32_t kPass = R * T;                    // list entries per pass
     constexpr uint32_t kWaves = T / 64;
-    constexpr uint32_t kListLen = kPass + 64;            // references a cluster's list can hold: a pass plus what was carried
-    static_assert(kPass + kFusedGroup * 64 <= 65536, "references are 16 bits wide");
-    __shared__ uint16_t list[kFusedGroup][kListLen];     // per cluster: references into at[]
-    __shared__ uint32_t at[kPass + kFusedGroup * 64];    // queue positions: this pass's entries, then 64 carried slots per cluster
-    __shared__ uint32_t cnt[kFusedGroup];                // length of each cluster's list
+    constexpr uint32_t kUnit = kPass / U;                // entries a scan unit looks at
+    static_assert(kUnit % 64 == 0 && kPass <= 65536, "units are whole 64-entry blocks; entry numbers are 16 bits wide");
+    __shared__ float4 ray_s[2 * kPass];                  // this pass's rays: origin + hit slot, direction + cut-off
+    __shared__ uint16_t mask_s[kPass];                   // the clusters of the group each entry's ray touches
+    __shared__ uint16_t refs_s[kWaves][kUnit];           // per wavefront: the entries of the unit it scans
     __shared__ uint32_t first_run[kFusedMaxGroups + 1];  // runs of the groups before each group
-    __shared__ uint32_t run_entries_s;
+    __shared__ uint32_t run_entries_s, next_unit;
 
     // ---- plan: the groups' lists are cut into runs of `run_entries` entries (a multiple of kPass),
     // sized so that every workgroup of the grid gets about one run; every workgroup computes the same plan
@@ -553,6 +642,8 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
     __syncthreads();
     const uint32_t n_runs = first_run[n_groups], run_entries = run_entries_s;
     const uint32_t n_pairs = (n_tri + 1) / 2;
+    const uint32_t my_pair = lane & 7u, my_ray = lane >> 3;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
 
     for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
         // the group this run belongs to (first_run is non-decreasing; n_groups <= 64: one ballot)
@@ -565,12 +656,9 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
         const uint32_t boxes = min(group_clusters, n_clusters - first_cluster);
         const uint32_t real = (1u << boxes) - 1u;          // an odd count leaves half a box pair without a box
         const uint32_t* __restrict__ my_list = grp_list + (size_t)g * list_capacity;
-        if (threadIdx.x < kFusedGroup) cnt[threadIdx.x] = 0;
-        uint32_t carried = 0; // threads 0..15: references their cluster's list held before this pass
-        __syncthreads();
 
         for (uint32_t pass = run_begin; pass < run_end; pass += kPass) {
-            // ---- bin this pass's entries into the clusters' lists
+            // ---- bin: this pass's rays into LDS, their cluster masks beside them
             SlabRay ray[R];
             bool active[R];
 #pragma unroll
@@ -578,62 +666,66 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
                 const uint32_t e = pass + i * T + threadIdx.x;
                 active[i] = e < run_end;
                 const uint32_t pos = my_list[active[i] ? e : run_end - 1];
-                at[i * T + threadIdx.x] = pos;
-                ray[i] = slab_ray(q_o[2 * (size_t)pos], q_d[2 * (size_t)pos]);
+                const float4 o4 = q_o[2 * (size_t)pos], d4 = q_d[2 * (size_t)pos];
+                ray_s[2 * (i * T + threadIdx.x)] = o4;
+                ray_s[2 * (i * T + threadIdx.x) + 1] = d4;
+                ray[i] = slab_ray(o4, d4);
             }
             uint32_t bits[R];
             slab_bits<R>(cl_pair + 6 * (size_t)(first_cluster / 2), 0, (boxes + 1) / 2, ray, bits);
 #pragma unroll
-            for (int i = 0; i < R; i++)
-                for (uint32_t m = active[i] ? (bits[i] & real) : 0u; m; m &= m - 1) {
-                    const uint32_t c = (uint32_t)__ffs((int)m) - 1u;
-                    list[c][atomicAdd(&cnt[c], 1u)] = (uint16_t)(i * T + threadIdx.x);
-                }
+            for (int i = 0; i < R; i++) mask_s[i * T + threadIdx.x] = (uint16_t)(active[i] ? (bits[i] & real) : 0u);
+            if (threadIdx.x == 0) next_unit = 0;
             __syncthreads();
-            // ---- scan: (cluster, 64 references) jobs, full ones only unless this is the run's last pass
-            const bool last = pass + kPass >= run_end;
-            const uint32_t len = lane < boxes ? cnt[lane] : 0;
-            if (cl_stat && threadIdx.x < boxes) // statistics: ray-cluster pairs listed in this pass
-                atomicAdd(&cl_stat[(size_t)(first_cluster + threadIdx.x) * kCountStride], len - carried);
-            const uint32_t jobs = last ? (len + 63) / 64 : len / 64;
-            uint32_t incl = jobs;
-#pragma unroll
-            for (int step = 1; step < (int)kFusedGroup; step <<= 1) {
-                const uint32_t up = __shfl_up(incl, step);
-                if ((int)lane >= step) incl += up;
-            }
-            const uint32_t before = incl - jobs;                 // lanes 0..15: jobs of the clusters before mine
-            const uint32_t n_jobs = __shfl(incl, kFusedGroup - 1);
-            for (uint32_t j = wave; j < n_jobs; j += kWaves) {
-                const uint32_t c = (uint32_t)__popcll(__ballot(lane < kFusedGroup && before <= j)) - 1u;
-                const uint32_t entry = (j - __shfl(before, (int)c)) * 64 + lane;
-                const bool valid = entry < __shfl(len, (int)c);
-                const uint32_t pos = at[list[c][valid ? entry : 0]];
-                const float4 o4 = q_o[2 * (size_t)pos];
-                const float4 d4 = q_d[2 * (size_t)pos];
-                Nearest best = nearest_init(d4.w);
+
+            // ---- scan: (cluster, part of the pass) units.  A wavefront works as 8 pairs x 8 rays.
+            const uint32_t n_units = U * boxes;
+            PendingHit pend;
+            pend.num = 0.f; pend.den = 1.f; pend.orig = 0xffffffffu; pend.slot = 0;
+            for (;;) {
+                uint32_t unit = 0;
+                if (lane == 0) unit = atomicAdd(&next_unit, 1u);
+                unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+                if (unit >= n_units) break;
+                const uint32_t c = unit / U, part = unit % U;
                 const uint32_t first = (first_cluster + c) * cluster_pairs;
-                scan_pairs(tri2, tri_orig, first, min(first + cluster_pairs, n_pairs), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, best);
-                if (valid && best.index >= 0) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(hit_distance(best)) << 32) | tri_orig[best.index];
-                    atomicMin(&hit[__float_as_uint(o4.w)], key);
+                const uint32_t last = min(first + cluster_pairs, n_pairs) - 1u; // the cluster's last pair
+                // this lane's pair of the cluster's first eight, requested before the work that hides its latency;
+                // lanes past the cluster's end repeat its last pair: the same hits once more, which the atomic minimum absorbs
+                uint32_t j = min(first + my_pair, last);
+                PairData pd = load_pair(tri2, j);
+                uint2 orig = reinterpret_cast<const uint2*>(tri_orig)[j];
+                // the unit's entries, in entry order, into this wavefront's list
+                uint32_t n = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < kUnit / 64; b++) {
+                    const uint32_t e = part * kUnit + b * 64 + lane;
+                    const bool touches = (mask_s[e] >> c) & 1u;
+                    const unsigned long long m = __ballot(touches);
+                    if (touches) refs_s[wave][n + (uint32_t)__popcll(m & below)] = (uint16_t)e;
+                    n += (uint32_t)__popcll(m);
+                }
+                if (n == 0) continue;
+                if (cl_stat && lane == 0) atomicAdd(&cl_stat[(size_t)(first_cluster + c) * kCountStride], n); // statistics
+                for (uint32_t chunk = first;;) {
+                    for (uint32_t k0 = 0; k0 < n; k0 += 8) {
+                        const uint32_t k = k0 + my_ray;
+                        const uint32_t e = refs_s[wave][min(k, n - 1u)];
+                        const float4 o4 = ray_s[2 * e], d4 = ray_s[2 * e + 1];
+                        pair_hits(pd, k < n, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, d4.w, [&](int h, float num, float den) {
+                            flush_hit(pend, hit); // (rare: an earlier hit of this lane is still pending)
+                            pend.num = num; pend.den = den; pend.slot = __float_as_uint(o4.w);
+                            pend.orig = h ? orig.y : orig.x;
+                        });
+                    }
+                    chunk += 8; // clusters of more than eight pairs: the next eight
+                    if (chunk > last) break;
+                    j = min(chunk + my_pair, last);
+                    pd = load_pair(tri2, j);
+                    orig = reinterpret_cast<const uint2*>(tri_orig)[j];
                 }
             }
-            __syncthreads();
-            // ---- carry: the references past the last full job move to the front of their list, their
-            // queue positions into the cluster's carried slots (a wavefront per cluster: it reads before it writes)
-            for (uint32_t c = wave; c < boxes; c += kWaves) {
-                const uint32_t n = cnt[c];
-                const uint32_t keep = last ? 0 : n % 64;
-                uint32_t pos = 0;
-                if (lane < keep) pos = at[list[c][n - keep + lane]];
-                if (lane < keep) {
-                    at[kPass + c * 64 + lane] = pos;
-                    list[c][lane] = (uint16_t)(kPass + c * 64 + lane);
-                }
-                if (lane == 0) cnt[c] = keep;
-            }
-            if (threadIdx.x < kFusedGroup) carried = last ? 0 : len % 64;
+            flush_hit(pend, hit);
             __syncthreads();
         }
     }

@@ -354,7 +354,7 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
                 // two passes and the runs even out (768 / 3 072 / 6 144 workgroups: 1.20 / 0.90 / 0.87 ms).
                 static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
                 const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : batch_paths >= 6u * 1024u * 1024u ? 6144u : batch_paths >= 2u * 1024u * 1024u ? 3072u : 1024u;
-                hipLaunchKernelGGL((k_group_clusters<2, 512>), dim3(grid), dim3(512), 0, stream,
+                hipLaunchKernelGGL((k_group_clusters<2, 512, 2>), dim3(grid), dim3(512), 0, stream,
                                    tri2, s->d.tri_orig, s->d.n_triangles, nc,
                                    s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
                                    (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,
