@@ -95,6 +95,17 @@ typedef struct rt_options {
      * zero weight would have met a light at distance exactly zero (the
      * reference then adds 0 x inf = NaN). */
     int32_t cluster_culling;
+    /* 0 (the default): the reference's float arithmetic operation by operation -- separately rounded
+     * products and sums, IEEE square roots and quotients, the double-precision scalars of
+     * src/raytrace.cu:358,360 -- with fixed polynomial log / sin / cos; the image equals a C restatement
+     * of the reference compiled without contraction, bit for bit, on any device and batch layout.
+     * 1: the same expressions as the hardware computes them fastest -- fused multiply-adds, reciprocal,
+     * reciprocal-square-root and square-root instructions (one unit in the last place), hardware
+     * log / sin / cos in the samplers -- which is also how the reference's own build computes (nvcc
+     * contracts by default and the kernel calls __logf / __cosf / __sinf / __powf, src/raytrace.cu:37-41,
+     * 46-49).  Per-pixel values without random numbers agree with mode 0 to about 1e-5 relative except
+     * where a hit-or-miss decision flips at an edge; images with random numbers agree in the mean. */
+    int32_t arithmetic;
 } rt_options;
 
 /* Work executed by the most recent render / accumulate call. */

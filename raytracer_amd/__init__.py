@@ -56,7 +56,7 @@ class Options(C.Structure):
     _fields_ = [
         ("indirect", C.c_int32), ("antialiasing", C.c_int32), ("bounding_box", C.c_int32),
         ("max_depth", C.c_int32), ("seed", C.c_uint32), ("profile", C.c_int32),
-        ("cluster_culling", C.c_int32),
+        ("cluster_culling", C.c_int32), ("arithmetic", C.c_int32),
     ]
 
 
@@ -72,9 +72,10 @@ class Stats(C.Structure):
 
 
 def make_options(indirect=True, antialiasing=True, bounding_box=True, max_depth=5, seed=1, profile=False,
-                 cluster_culling=True) -> Options:
+                 cluster_culling=True, arithmetic=0) -> Options:
+    """arithmetic: 0 = the reference's float arithmetic bit for bit, 1 = fused multiply-adds and hardware reciprocals / roots."""
     return Options(int(indirect), int(antialiasing), int(bounding_box), int(max_depth), int(seed) & 0xFFFFFFFF, int(profile),
-                   int(cluster_culling))
+                   int(cluster_culling), int(arithmetic))
 
 
 class RtError(RuntimeError):

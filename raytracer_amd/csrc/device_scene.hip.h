@@ -154,6 +154,61 @@ __device__ __forceinline__ V3 normalize(V3 a) {
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+
+// ---- the two arithmetics of the path kernels --------------------------------
+//
+// ExactMath is the reference's float arithmetic operation by operation: separately rounded products
+// and sums, IEEE square roots and quotients, the double-precision scalars of src/raytrace.cu:358,360
+// and the polynomial log / sin / cos of rt_math.h -- the image equals the CPU restatement's bit for bit.
+// FastMath (rt_options.arithmetic = 1) computes the same expressions the way the hardware likes them:
+// fused multiply-adds, v_rsq_f32 / v_rcp_f32 / v_sqrt_f32 (one unit in the last place each) instead of
+// the IEEE expansions, |OC|^2 as a dot product instead of a square root squared, the light term in
+// single precision, hardware log / sin / cos for the samplers -- as the reference itself does on its
+// hardware (nvcc contracts by default; __logf, __cosf, __sinf, __powf in src/raytrace.cu:37-41,46-49).
+// Every quantity is within a few 1e-7 (relative) of the exact one; pixels differ by more only where a
+// ray's hit-or-miss decision flips at an edge.
+struct ExactMath { static constexpr bool kExact = true; };
+struct FastMath { static constexpr bool kExact = false; };
+
+__device__ __forceinline__ float fast_dot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+template <class M> __device__ __forceinline__ float dot_m(V3 a, V3 b) {
+    if constexpr (M::kExact) return dot(a, b); else return fast_dot(a, b);
+}
+template <class M> __device__ __forceinline__ float sqrt_m(float x) {
+    if constexpr (M::kExact) return sqrt_rn(x); else return __builtin_amdgcn_sqrtf(x);
+}
+template <class M> __device__ __forceinline__ float div_m(float a, float b) {
+    if constexpr (M::kExact) return a / b; else return a * __builtin_amdgcn_rcpf(b);
+}
+template <class M> __device__ __forceinline__ float norm_m(V3 a) {
+    if constexpr (M::kExact) return norm(a); else return __builtin_amdgcn_sqrtf(fast_dot(a, a));
+}
+template <class M> __device__ __forceinline__ V3 normalize_m(V3 a) {
+    if constexpr (M::kExact) {
+        return normalize(a);
+    } else {
+        const float r = __builtin_amdgcn_rsqf(fast_dot(a, a));
+        return mk(a.x * r, a.y * r, a.z * r);
+    }
+}
+template <class M> __device__ __forceinline__ V3 cross_m(V3 a, V3 b) {
+    if constexpr (M::kExact) return cross(a, b);
+    else return mk(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+// a + s * b
+template <class M> __device__ __forceinline__ V3 along_m(V3 a, float s, V3 b) {
+    if constexpr (M::kExact) return a + s * b;
+    else return mk(__builtin_fmaf(s, b.x, a.x), __builtin_fmaf(s, b.y, a.y), __builtin_fmaf(s, b.z, a.z));
+}
+// a + 0.01 * N with the reference's double-precision scalar (src/raytrace.cu:358,372,379)
+template <class M> __device__ __forceinline__ V3 offset_m(V3 a, float sign, V3 N) {
+    if constexpr (M::kExact) return sign > 0 ? a + scale_d(0.01, N) : a - scale_d(0.01, N);
+    else return along_m<M>(a, sign * 0.01f, N);
+}
+// |OC|^2 as the reference computes it: the norm, squared (src/raytrace.cu:62-66)
+template <class M> __device__ __forceinline__ float oc_norm2_m(V3 oc) {
+    if constexpr (M::kExact) { const float n = norm(oc); return n * n; } else return fast_dot(oc, oc);
+}
 __device__ __forceinline__ V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
 
 // ---------------------------------------------------------- intersection
@@ -248,10 +303,12 @@ __device__ __forceinline__ void for_each_box(const DeviceScene& sc, const SceneC
 
 // One sphere of the reference's scan (get_distance, src/raytrace.cu:59-84)
 // given b = u . OC and n2 = |OC| * |OC|.
+template <class M = ExactMath>
 __device__ __forceinline__ void sphere_step(float b, float n2, float R, uint32_t i, float& min_dist, int& id) {
-    const float delta = b * b - n2 + R * R;
+    float delta;
+    if constexpr (M::kExact) delta = b * b - n2 + R * R; else delta = __builtin_fmaf(R, R, __builtin_fmaf(b, b, -n2));
     if (delta >= 0) {
-        const float sq = sqrt_rn(delta);
+        const float sq = sqrt_m<M>(delta);
         const float t2 = -b + sq;
         if (t2 >= 0) {
             const float t1 = -b - sq;
@@ -273,8 +330,13 @@ __device__ __forceinline__ void sphere_step(float b, float n2, float R, uint32_t
 // or t1 < 0 and t2 > dist: never a hit nearer than the light.  On return min_dist < dist has the
 // value it has after the exact scan; min_dist and id themselves are only those of the spheres
 // that took the exact step.
+template <class M = ExactMath>
 __device__ __forceinline__ void sphere_step_shadow(float b, float n2, float R, uint32_t i, float dist, float half_dist, float& min_dist,
                                                    int& id) {
+    if constexpr (!M::kExact) { // the hardware square root is the arithmetic itself: nothing to certify
+        sphere_step<M>(b, n2, R, i, min_dist, id);
+        return;
+    }
     const float delta = b * b - n2 + R * R;
     if (delta >= 0) {
         const float root = __builtin_amdgcn_sqrtf(delta);
@@ -295,25 +357,25 @@ __device__ __forceinline__ void sphere_step_shadow(float b, float n2, float R, u
 }
 
 // Nearest sphere along a ray (reference get_distance, src/raytrace.cu:53-87).
+template <class M = ExactMath>
 __device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start, int& id) {
     float min_dist = INFINITY;
     for_each_sphere(sc, c, [&](uint32_t i, float4 s) {
         const V3 oc = start - xyz(s);
-        const float ocn = norm(oc);
-        sphere_step(dot(ray, oc), ocn * ocn, s.w, i, min_dist, id);
+        sphere_step<M>(dot_m<M>(ray, oc), oc_norm2_m<M>(oc), s.w, i, min_dist, id);
     });
     return min_dist;
 }
 
 // The scan of a shadow ray towards a light at distance light_dist: the returned value compares with
 // light_dist (<) as nearest_sphere's does, and says nothing else (sphere_step_shadow).
+template <class M = ExactMath>
 __device__ __forceinline__ float nearest_sphere_shadow(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start, float light_dist, int& id) {
     float min_dist = INFINITY;
     const float half = 0.5f * light_dist;
     for_each_sphere(sc, c, [&](uint32_t i, float4 s) {
         const V3 oc = start - xyz(s);
-        const float ocn = norm(oc);
-        sphere_step_shadow(dot(ray, oc), ocn * ocn, s.w, i, light_dist, half, min_dist, id);
+        sphere_step_shadow<M>(dot_m<M>(ray, oc), oc_norm2_m<M>(oc), s.w, i, light_dist, half, min_dist, id);
     });
     return min_dist;
 }
@@ -322,6 +384,7 @@ __device__ __forceinline__ float nearest_sphere_shadow(const DeviceScene& sc, co
 // light_dist and the bounce ray (b) of one hit: OC and its norm depend on the start only and are
 // computed once per sphere.  A ray whose flag is false keeps (inf, id); dist_a is good for the
 // comparison with light_dist only (sphere_step_shadow).
+template <class M = ExactMath>
 __device__ __forceinline__ void nearest_sphere_pair(const DeviceScene& sc, const SceneCache& c, V3 start, bool do_a, V3 ray_a,
                                                     float light_dist, float& dist_a, int& id_a, bool do_b, V3 ray_b, float& dist_b,
                                                     int& id_b) {
@@ -330,10 +393,9 @@ __device__ __forceinline__ void nearest_sphere_pair(const DeviceScene& sc, const
     const float half = 0.5f * light_dist;
     for_each_sphere(sc, c, [&](uint32_t i, float4 s) {
         const V3 oc = start - xyz(s);
-        const float ocn = norm(oc);
-        const float n2 = ocn * ocn;
-        if (do_a) sphere_step_shadow(dot(ray_a, oc), n2, s.w, i, light_dist, half, dist_a, id_a);
-        if (do_b) sphere_step(dot(ray_b, oc), n2, s.w, i, dist_b, id_b);
+        const float n2 = oc_norm2_m<M>(oc);
+        if (do_a) sphere_step_shadow<M>(dot_m<M>(ray_a, oc), n2, s.w, i, light_dist, half, dist_a, id_a);
+        if (do_b) sphere_step<M>(dot_m<M>(ray_b, oc), n2, s.w, i, dist_b, id_b);
     });
 }
 
@@ -391,6 +453,19 @@ __device__ __forceinline__ int box_verdict(V3 lo, V3 hi, V3 ray, float finite_pr
     return gap > 0.f ? 1 : 0;
 }
 
+// box_hit with reciprocals (FastMath): the same slabs, the same [0, 0] for an axis the ray is parallel to, the
+// same verdict min(exit) > max(entry); quotients within 2.4e-7 of the IEEE ones.
+__device__ __forceinline__ bool box_hit_fast(V3 lo, V3 hi, V3 ray) {
+    const float ix = __builtin_amdgcn_rcpf(ray.x), iy = __builtin_amdgcn_rcpf(ray.y), iz = __builtin_amdgcn_rcpf(ray.z);
+    float ax = lo.x * ix, bx = hi.x * ix, ay = lo.y * iy, by = hi.y * iy, az = lo.z * iz, bz = hi.z * iz;
+    if (ray.x == 0) ax = bx = 0.f;
+    if (ray.y == 0) ay = by = 0.f;
+    if (ray.z == 0) az = bz = 0.f;
+    const float mn = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float mx = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    return mn > mx;
+}
+
 // (Out of line: the rare exact answer must not cost the callers registers.)
 __device__ __attribute__((noinline)) bool box_hit_out_of_line(float lx, float ly, float lz, float hx, float hy, float hz, float rx,
                                                               float ry, float rz) {
@@ -408,13 +483,14 @@ __device__ __forceinline__ bool box_hit_via_verdict(V3 lo, V3 hi, V3 ray, float 
 // the ray is parallel to the slab, there is no t > 0 requirement, and the
 // verdict is min(exit) > max(entry).
 // kViaVerdict: decide by box_verdict where that is certain (fewer instructions, more registers).
-template <bool kViaVerdict = false>
+template <bool kViaVerdict = false, class M = ExactMath>
 __device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start) {
     bool hit = false;
     for_each_box(sc, c, [&](float4 lo, float4 hi) {
         if (!hit) {
             const V3 l = xyz(lo) - start, h = xyz(hi) - start;
-            if (kViaVerdict) hit = box_hit_via_verdict(l, h, ray, ((l.x + l.y) + (l.z + h.x)) + (h.y + h.z));
+            if constexpr (!M::kExact) hit = box_hit_fast(l, h, ray);
+            else if (kViaVerdict) hit = box_hit_via_verdict(l, h, ray, ((l.x + l.y) + (l.z + h.x)) + (h.y + h.z));
             else hit = box_hit(l, h, ray);
         }
     });
@@ -502,14 +578,15 @@ __device__ __forceinline__ void add_casts(const Work& w, uint32_t counter, uint3
 
 // True when the ray has to walk the triangle list (reference
 // src/raytrace.cu:103-146: with boxes enabled only after a box hit).
-template <bool kViaVerdict = false>
+template <bool kViaVerdict = false, class M = ExactMath>
 __device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, const SceneCache& c, int use_boxes, V3 ray, V3 start) {
     if (sc.n_triangles == 0) return false;
     if (!use_boxes) return true;
-    return any_box_hit<kViaVerdict>(sc, c, ray, start);
+    return any_box_hit<kViaVerdict, M>(sc, c, ray, start);
 }
 
 // needs_mesh for two rays that leave the same point; box - start is shared.
+template <class M = ExactMath>
 __device__ __forceinline__ void needs_mesh_pair(const DeviceScene& sc, const SceneCache& c, int use_boxes, V3 start, bool do_a, V3 ray_a,
                                                 bool& walk_a, bool do_b, V3 ray_b, bool& walk_b) {
     walk_a = false;
@@ -519,20 +596,32 @@ __device__ __forceinline__ void needs_mesh_pair(const DeviceScene& sc, const Sce
     for_each_box(sc, c, [&](float4 bmin, float4 bmax) {
         const V3 lo = xyz(bmin) - start;
         const V3 hi = xyz(bmax) - start;
-        if (do_a && !walk_a) walk_a = box_hit(lo, hi, ray_a);
-        if (do_b && !walk_b) walk_b = box_hit(lo, hi, ray_b);
+        if constexpr (M::kExact) {
+            if (do_a && !walk_a) walk_a = box_hit(lo, hi, ray_a);
+            if (do_b && !walk_b) walk_b = box_hit(lo, hi, ray_b);
+        } else {
+            if (do_a && !walk_a) walk_a = box_hit_fast(lo, hi, ray_a);
+            if (do_b && !walk_b) walk_b = box_hit_fast(lo, hi, ray_b);
+        }
     });
 }
 
 // Barycentrics of a known hit, by the expressions of the reference's triangle
 // loop (src/raytrace.cu:155-164).
+template <class M = ExactMath>
 __device__ __forceinline__ void barycentrics(const DeviceScene& sc, int tri, V3 ray, V3 start, float& alpha, float& beta, float& gamma) {
     const float4 g0 = sc.tri_geom[3 * tri + 0], g1 = sc.tri_geom[3 * tri + 1], g2 = sc.tri_geom[3 * tri + 2];
     const V3 A = mk(g0.x, g0.y, g0.z), e1 = mk(g0.w, g1.x, g1.y), e2 = mk(g1.z, g1.w, g2.x), N = mk(g2.y, g2.z, g2.w);
-    const V3 q = cross(A - start, ray);
-    const float d = dot(ray, N);
-    beta = dot(e2, q) / d;
-    gamma = -dot(e1, q) / d;
+    const V3 q = cross_m<M>(A - start, ray);
+    if constexpr (M::kExact) {
+        const float d = dot(ray, N);
+        beta = dot(e2, q) / d;
+        gamma = -dot(e1, q) / d;
+    } else {
+        const float r = __builtin_amdgcn_rcpf(fast_dot(ray, N));
+        beta = fast_dot(e2, q) * r;
+        gamma = -fast_dot(e1, q) * r;
+    }
     alpha = 1.f - beta - gamma;
 }
 

@@ -15,7 +15,7 @@
 namespace {
 
 const char* kUsage =
-    "usage: render [scene.json] [--direct] [--no-aa] [--no-bbox] [--exhaustive] [--depth N] [--seed N]\n"
+    "usage: render [scene.json] [--direct] [--no-aa] [--no-bbox] [--exhaustive] [--fast] [--depth N] [--seed N]\n"
     "              [-o image.png|image.pfm] [--devices N]\n"
     "              [--frames N --rotate RX RY RZ --move DX DY DZ --first K --stride S --writers T]\n"
     "  with --frames, -o is a pattern such as frames/frame_%04d.png\n"
@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
         else if (a == "--no-aa") s.settings.antialiasing = false;
         else if (a == "--no-bbox") s.settings.bounding_box = false;
         else if (a == "--exhaustive") s.settings.cluster_culling = false;
+        else if (a == "--fast") s.settings.fast_arithmetic = true;
         else if (a == "--depth" && i + 1 < argc) s.settings.max_ray_depth = std::atoi(argv[++i]);
         else if (a == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
         else if (a == "-o" && i + 1 < argc) out = argv[++i];

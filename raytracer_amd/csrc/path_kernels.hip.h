@@ -83,7 +83,40 @@ __device__ __forceinline__ void jitter_exact(const rt_rng_key& key, uint32_t dim
     dy = radius * sn * 1.f;
 }
 
-template <uint32_t kPaths>
+// The same Box-Muller pair from the hardware's log2 / sin / cos (arguments in turns), as the reference takes it
+// from __logf / __cosf / __sinf: absolute error of the offsets far below 1e-4 of a pixel.
+__device__ __forceinline__ void jitter_fast(const rt_rng_key& key, uint32_t dim, float& dx, float& dy) {
+    const float r1 = rt_rng_uniform(key, dim);
+    const float r2 = rt_rng_uniform(key, dim + 1);
+    const float radius = __builtin_amdgcn_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1)); // -2 ln 2 * log2(r1)
+    dx = radius * __builtin_amdgcn_cosf(r2);
+    dy = radius * __builtin_amdgcn_sinf(r2);
+}
+
+template <class M> __device__ __forceinline__ void jitter_m(const rt_rng_key& key, uint32_t dim, float& dx, float& dy) {
+    if constexpr (M::kExact) jitter_exact(key, dim, dx, dy); else jitter_fast(key, dim, dx, dy);
+}
+
+// Is the draw at `dim` accepted (both offsets within half a pixel, src/raytrace.cu:483-486)?  ExactMath: classified
+// with the hardware transcendentals where that is certain, by the reference's own arithmetic within 1e-4 of the limit.
+// FastMath: the hardware values are the arithmetic.
+template <class M> __device__ __forceinline__ bool jitter_accepted(const rt_rng_key& key, uint32_t dim) {
+    const float r1 = rt_rng_uniform(key, dim);
+    if (!(r1 >= 0.77f)) return false; // radius > 0.722: one offset exceeds 0.5
+    const float r2 = rt_rng_uniform(key, dim + 1);
+    float radius;
+    if constexpr (M::kExact) radius = __builtin_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1)); // -2 ln 2 * log2(r1)
+    else radius = __builtin_amdgcn_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1));
+    const float m = fmaxf(fabsf(radius * __builtin_amdgcn_cosf(r2)), fabsf(radius * __builtin_amdgcn_sinf(r2))); // argument in turns
+    if constexpr (!M::kExact) return !(m > 0.5f);
+    if (m < 0.4999f) return true;
+    if (m > 0.5001f) return false;
+    float dx, dy;
+    jitter_exact(key, dim, dx, dy);
+    return !(fabsf(dx) > 0.5f || fabsf(dy) > 0.5f);
+}
+
+template <uint32_t kPaths, class M>
 __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f) {
     __shared__ SceneCache cache;
     __shared__ uint32_t key_kp[kPaths][kBlock], key_ks[kPaths][kBlock];
@@ -94,8 +127,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
     // for all paths and is computed once per workgroup (same operations, same bits)
     if (threadIdx.x < min(sc.n_spheres, kSphereCache)) {
         const V3 oc = mk(f.pos[0], f.pos[1], f.pos[2]) - xyz(cache.sphere[threadIdx.x]);
-        const float ocn = norm(oc);
-        eye_oc[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, ocn * ocn);
+        eye_oc[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, oc_norm2_m<M>(oc));
     }
     __syncthreads();
     const uint32_t base = blockIdx.x * (kBlock * kPaths) + threadIdx.x;
@@ -118,21 +150,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
         key.kp = key_kp[0][threadIdx.x];
         key.ks = key_ks[0][threadIdx.x];
         while (r < owned) {
-            const float r1 = rt_rng_uniform(key, dim);
-            bool accept = false;
-            if (r1 >= 0.77f) {
-                const float r2 = rt_rng_uniform(key, dim + 1);
-                const float radius = __builtin_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1)); // -2 ln 2 * log2(r1)
-                const float m = fmaxf(fabsf(radius * __builtin_amdgcn_cosf(r2)), fabsf(radius * __builtin_amdgcn_sinf(r2))); // argument in turns
-                if (m < 0.4999f) {
-                    accept = true;
-                } else if (!(m > 0.5001f)) {
-                    float dx, dy;
-                    jitter_exact(key, dim, dx, dy);
-                    accept = !(fabsf(dx) > 0.5f || fabsf(dy) > 0.5f);
-                }
-            }
-            if (accept) {
+            if (jitter_accepted<M>(key, dim)) {
                 accepted[r][threadIdx.x] = dim;
                 r++;
                 dim = 0;
@@ -161,15 +179,15 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
                 key.kp = key_kp[r][threadIdx.x];
                 key.ks = key_ks[r][threadIdx.x];
                 dim = accepted[r][threadIdx.x];
-                jitter_exact(key, dim, dx, dy);
+                jitter_m<M>(key, dim, dx, dy);
                 dim += 2;
             }
             const float px = (float)ux + 0.5f + dx;
             const float py = (float)uy + 0.5f + dy;
-            const V3 dir = normalize(mk((px - f.cx) / f.fx, (py - f.cy) / f.fy, 1.f));
-            ray = mk(dot(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
-                     dot(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
-                     dot(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
+            const V3 dir = normalize_m<M>(mk(div_m<M>(px - f.cx, f.fx), div_m<M>(py - f.cy, f.fy), 1.f));
+            ray = mk(dot_m<M>(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
+                     dot_m<M>(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
+                     dot_m<M>(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
             w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
             w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
         }
@@ -181,15 +199,14 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             const uint32_t cached = min(sc.n_spheres, kSphereCache);
             for (uint32_t i = 0; i < cached; i++) {
                 const float4 e = eye_oc[i];
-                sphere_step(dot(ray, xyz(e)), e.w, cache.sphere[i].w, i, ts, sid);
+                sphere_step<M>(dot_m<M>(ray, xyz(e)), e.w, cache.sphere[i].w, i, ts, sid);
             }
             for (uint32_t i = cached; i < sc.n_spheres; i++) {
                 const float4 sph = sc.sphere[i];
                 const V3 oc = start - xyz(sph);
-                const float ocn = norm(oc);
-                sphere_step(dot(ray, oc), ocn * ocn, sph.w, i, ts, sid);
+                sphere_step<M>(dot_m<M>(ray, oc), oc_norm2_m<M>(oc), sph.w, i, ts, sid);
             }
-            walk = needs_mesh<true>(sc, cache, f.bounding_box, ray, start);
+            walk = needs_mesh<true, M>(sc, cache, f.bounding_box, ray, start);
         }
         commit_ray(w, 0, alive, p, start, ray, ts, sid, walk);
         n_casts += (uint32_t)__popcll(__ballot(alive));
@@ -220,14 +237,20 @@ __device__ __forceinline__ V3 settle_pending(const DeviceScene& sc, const Work& 
 // cosine-weighted direction about N (reference random_cos,
 // src/raytrace.cu:253-296, with argmin_abs of include/vector.cuh:87-98: the
 // running minimum starts at the signed first component)
+template <class M = ExactMath>
 __device__ __forceinline__ V3 random_cos(float r1, float r2, V3 N) {
-    const float tmp1 = sqrt_rn(1 - r2);
-    const float tmp2 = (float)(2 * M_PI * (double)r1);
+    const float tmp1 = sqrt_m<M>(1 - r2);
     float sn, cs;
-    rt_sincosf(tmp2, &sn, &cs);
+    if constexpr (M::kExact) {
+        const float tmp2 = (float)(2 * M_PI * (double)r1);
+        rt_sincosf(tmp2, &sn, &cs);
+    } else { // the hardware's sine and cosine take the angle in turns
+        sn = __builtin_amdgcn_sinf(r1);
+        cs = __builtin_amdgcn_cosf(r1);
+    }
     const float x = tmp1 * cs;
     const float y = tmp1 * sn;
-    const float z = sqrt_rn(r2);
+    const float z = sqrt_m<M>(r2);
     const float n[3] = {N.x, N.y, N.z};
     float m = n[0];
     int k = 0;
@@ -238,18 +261,24 @@ __device__ __forceinline__ V3 random_cos(float r1, float r2, V3 N) {
     if (k == 0) T1 = mk(0.f, N.z, -N.y);       // (i, j) = (1, 2)
     else if (k == 1) T1 = mk(-N.z, 0.f, N.x);  // (i, j) = (2, 0)
     else T1 = mk(N.y, -N.x, 0.f);              // (i, j) = (0, 1)
-    T1 = normalize(T1);
-    const V3 T2 = normalize(cross(N, T1));
-    return (x * T1 + y * T2) + z * N;
+    T1 = normalize_m<M>(T1);
+    const V3 T2 = normalize_m<M>(cross_m<M>(N, T1));
+    if constexpr (M::kExact) return (x * T1 + y * T2) + z * N;
+    else return along_m<M>(along_m<M>(x * T1, y, T2), z, N);
 }
 
-__device__ __forceinline__ V3 reflect(V3 ray, V3 N) { return ray - (2 * dot(ray, N)) * N; }
+template <class M = ExactMath>
+__device__ __forceinline__ V3 reflect(V3 ray, V3 N) {
+    if constexpr (M::kExact) return ray - (2 * dot(ray, N)) * N;
+    else return along_m<M>(ray, -2.f * fast_dot(ray, N), N);
+}
 
 // The material's response to a hit at P with shading normal N (reference get_color,
 // src/raytrace.cu:338-437): the point and direction the path continues from, whether the lights are
 // evaluated here (`lit`: diffuse hit), whether the path goes on (`alive`) and whether its weight
 // picks up the surface colour (`tinted`).  `ray` is the incoming direction on entry.  N comes back
 // flipped when a glass surface is left from the inside.
+template <class M = ExactMath>
 __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const SceneCache& cache, const Frame& f, const rt_rng_key& rng,
                                                int depth, int m, V3 P, V3& N, V3& start, V3& ray, V3 weight, V3& colour,
                                                uint32_t& dim, uint32_t& flags, bool& alive, bool& lit, bool& tinted) {
@@ -263,7 +292,7 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
         if (!f.indirect && depth == 0) flags |= F_EARLY;
         if (f.antialiasing) flags &= ~F_EARLY;
         lit = true;
-        start = P + scale_d(0.01, N);
+        start = offset_m<M>(P, 1.f, N);
         if (!f.indirect) {
             alive = false;
         } else {
@@ -273,44 +302,44 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
                 const float r1 = rt_rng_uniform(rng, dim);
                 const float r2 = rt_rng_uniform(rng, dim + 1);
                 dim += 2;
-                ray = random_cos(r1, r2, N);
+                ray = random_cos<M>(r1, r2, N);
             }
         }
     } else if (type == RT_MIRROR) {
-        const V3 rr = reflect(ray, N);
-        start = P + scale_d(0.01, N);
+        const V3 rr = reflect<M>(ray, N);
+        start = offset_m<M>(P, 1.f, N);
         ray = rr;
     } else { // RT_GLASS
         const float2 ior = material_ior(sc, cache, (uint32_t)m);
         float ro = ior.x, ri = ior.y;
-        float wn = dot(ray, N);
+        float wn = dot_m<M>(ray, N);
         // Schlick reflectance (reference src/raytrace.cu:388-394)
-        const float k0 = (ro - ri) * (ro - ri) / ((ro + ri) * (ro + ri));
+        const float k0 = div_m<M>((ro - ri) * (ro - ri), (ro + ri) * (ro + ri));
         const float om = 1.f - fabsf(wn);
         const float om2 = om * om;
         const float R = k0 + (1.f - k0) * om2 * om2 * om;
         const float r = rt_rng_uniform(rng, dim);
         dim += 1;
         if (r < R) {
-            const V3 rr = reflect(ray, N);
-            start = P + scale_d(0.01, N);
+            const V3 rr = reflect<M>(ray, N);
+            start = offset_m<M>(P, 1.f, N);
             ray = rr;
         } else {
             if (wn > 0) { // leaving the medium: swap indices, flip the normal
                 const float sw = ro; ro = ri; ri = sw;
                 N = -1.f * N;
-                wn = dot(ray, N);
+                wn = dot_m<M>(ray, N);
             }
-            const float eta = ro / ri;
+            const float eta = div_m<M>(ro, ri);
             const float k = 1.f - eta * eta * (1.f - wn * wn);
             if (k < 0) { // total internal reflection
-                const V3 rr = reflect(ray, N);
-                start = P + scale_d(0.01, N);
+                const V3 rr = reflect<M>(ray, N);
+                start = offset_m<M>(P, 1.f, N);
                 ray = rr;
             } else {
                 const V3 wt_t = eta * (ray - wn * N);
-                const V3 wt_n = (-sqrt_rn(k)) * N;
-                start = P - scale_d(0.01, N);
+                const V3 wt_n = (-sqrt_m<M>(k)) * N;
+                start = offset_m<M>(P, -1.f, N);
                 ray = wt_t + wt_n;
             }
         }
@@ -331,8 +360,8 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
 // the sphere scans and box tests of the shadow rays (diffuse hits) and of the
 // bounce ray.  The first light's shadow ray and the bounce ray of a diffuse
 // hit leave the same point, so their scans run as one (nearest_sphere_pair).
-// (At least five wavefronts per SIMD: 96 VGPRs.  One register more would cost a fifth of the occupancy.)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
+template <class M>
+__device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& w, const Frame& f, int depth) {
     __shared__ SceneCache cache;
     // The first bounce sees every path; later ones walk the list of paths the previous bounce
     // left alive, so that the lanes of a wavefront are all busy however many paths have ended.
@@ -397,22 +426,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
             if (tt < min_dist) { min_dist = tt; sid = -1; tid = tmp; }
 
             if (sid >= 0 || tid >= 0) {
-                P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : start + min_dist * ray;
+                P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : along_m<M>(start, min_dist, ray);
                 int m;
                 if (sid >= 0) {
                     m = sphere_material(sc, cache, (uint32_t)sid);
-                    N = normalize(P - xyz(sphere_at(sc, cache, (uint32_t)sid)));
+                    N = normalize_m<M>(P - xyz(sphere_at(sc, cache, (uint32_t)sid)));
                 } else {
                     float alpha, beta, gamma;
-                    barycentrics(sc, tid, ray, start, alpha, beta, gamma);
+                    barycentrics<M>(sc, tid, ray, start, alpha, beta, gamma);
                     const float4 s0 = sc.tri_shade[3 * tid + 0], s1 = sc.tri_shade[3 * tid + 1], s2 = sc.tri_shade[3 * tid + 2];
                     m = __float_as_int(s0.w);
-                    N = normalize((alpha * xyz(s0) + beta * xyz(s1)) + gamma * xyz(s2));
+                    if constexpr (M::kExact) N = normalize((alpha * xyz(s0) + beta * xyz(s1)) + gamma * xyz(s2));
+                    else N = normalize_m<M>(along_m<M>(along_m<M>(alpha * xyz(s0), beta, xyz(s1)), gamma, xyz(s2)));
                 }
                 weight = xyz(th);
                 uint32_t dim = __float_as_uint(th.w);
                 const rt_rng_key rng = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
-                respond_to_hit(sc, cache, f, rng, depth, m, P, N, start, ray, weight, colour, dim, flags, alive, lit, tinted);
+                respond_to_hit<M>(sc, cache, f, rng, depth, m, P, N, start, ray, weight, colour, dim, flags, alive, lit, tinted);
                 next_dim = dim;
             }
         }
@@ -436,29 +466,47 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
         const float4 li = light_at(sc, cache, l);
         const V3 lp = xyz(li);
         const V3 sp_ = lp - P;
-        const float d = norm(sp_);
-        const V3 wi = (1.f / d) * sp_;
-        const float nwi = fmaxf(dot(N, wi), 0.f);
-        const V3 sray = normalize(lp - start);
-        const float dist = norm(lp - start);
+        V3 wi, sray;
+        float d, dist;
+        if constexpr (M::kExact) {
+            d = norm(sp_);
+            wi = (1.f / d) * sp_;
+            sray = normalize(lp - start);
+            dist = norm(lp - start);
+        } else { // one reciprocal square root per vector serves its length and its direction
+            const float d2 = fast_dot(sp_, sp_), rd = __builtin_amdgcn_rsqf(d2);
+            d = d2 * rd;
+            wi = rd * sp_;
+            const V3 ls = lp - start;
+            const float l2 = fast_dot(ls, ls), rl = __builtin_amdgcn_rsqf(l2);
+            dist = l2 * rl;
+            sray = rl * ls;
+        }
+        const float nwi = fmaxf(dot_m<M>(N, wi), 0.f);
         float ds = INFINITY;
         int shadow_sid = -1;
         bool shadow_walk = false;
         if (l == 0) {
-            nearest_sphere_pair(sc, cache, start, lit, sray, dist, ds, shadow_sid, alive, ray, ts, sid);
-            needs_mesh_pair(sc, cache, f.bounding_box, start, lit && !(ds < dist), sray, shadow_walk, alive, ray, walk);
+            nearest_sphere_pair<M>(sc, cache, start, lit, sray, dist, ds, shadow_sid, alive, ray, ts, sid);
+            needs_mesh_pair<M>(sc, cache, f.bounding_box, start, lit && !(ds < dist), sray, shadow_walk, alive, ray, walk);
             bounce_probed = true;
         } else if (lit) {
-            ds = nearest_sphere_shadow(sc, cache, sray, start, dist, shadow_sid);
-            shadow_walk = !(ds < dist) && needs_mesh(sc, cache, f.bounding_box, sray, start);
+            ds = nearest_sphere_shadow<M>(sc, cache, sray, start, dist, shadow_sid);
+            shadow_walk = !(ds < dist) && needs_mesh<false, M>(sc, cache, f.bounding_box, sray, start);
         }
         const size_t slot = (size_t)p * sc.n_lights + l;
         if (lit) {
             const bool blocked = ds < dist;
             // ((I / (4 pi^2 d^2) * colour) * visible) * N.wi, the first
             // factor in double (reference src/raytrace.cu:360)
-            const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
-            const V3 direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
+            V3 direct;
+            if constexpr (M::kExact) {
+                const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
+                direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
+            } else {
+                const float q = li.w * __builtin_amdgcn_rcpf((float)(4 * M_PI * M_PI) * d * d);
+                direct = (blocked ? 0.f : nwi * q) * colour;
+            }
             const V3 c = weight * direct;
             // A contribution of exactly zero (light behind the surface, black surface) is the
             // same added or not: what the triangles would say about its shadow ray does not
@@ -493,13 +541,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
         w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
     }
     if (!bounce_probed && alive) { // a scene without lights
-        ts = nearest_sphere(sc, cache, ray, start, sid);
-        walk = needs_mesh(sc, cache, f.bounding_box, ray, start);
+        ts = nearest_sphere<M>(sc, cache, ray, start, sid);
+        walk = needs_mesh<false, M>(sc, cache, f.bounding_box, ray, start);
     }
     // (the product again rather than three registers kept across the lights: same operands, same bits)
     const V3 next_weight = tinted ? weight * colour : weight;
     finish_bounce(w, counter, last_want, start, last_sray, last_slot, last_dist, alive, walk, ray, ts, sid,
                   make_float4(next_weight.x, next_weight.y, next_weight.z, __uint_as_float(next_dim)), p | (deferred ? kLivePending : 0u));
+}
+
+// (At least five wavefronts per SIMD: 96 VGPRs.  One register more would cost a fifth of the occupancy.)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
+    shade_bounce<ExactMath>(sc, w, f, depth);
+}
+
+// rt_options.arithmetic = 1
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast(DeviceScene sc, Work w, Frame f, int depth) {
+    shade_bounce<FastMath>(sc, w, f, depth);
 }
 
 // ---- scenes without triangles: the whole sample loop in registers -------
@@ -516,6 +574,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
 // the run of searches, the closer the lanes of a wavefront finish together: 3 % of a 1 000-sample frame).
 constexpr uint32_t kTraceGroup = 4, kTraceSearch = 16;
 
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame f, uint32_t n_samples, float4* __restrict__ sum,
                                                           float4* __restrict__ rad, uint32_t* __restrict__ cast_count) {
     __shared__ SceneCache cache;
@@ -524,8 +583,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
     stage_scene(sc, cache);
     if (threadIdx.x < min(sc.n_spheres, kSphereCache)) {
         const V3 oc = mk(f.pos[0], f.pos[1], f.pos[2]) - xyz(cache.sphere[threadIdx.x]);
-        const float ocn = norm(oc);
-        eye_oc[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, ocn * ocn);
+        eye_oc[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, oc_norm2_m<M>(oc));
     }
     __syncthreads();
     // rad == nullptr: a lane owns a pixel and all n_samples samples, and keeps the running sum.
@@ -558,21 +616,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
             uint32_t r = 0, dim = 0;
             rt_rng_key key = rt_rng_make_key(f.seed, pixel, f.sample_begin + s0);
             while (r < group) {
-                const float r1 = rt_rng_uniform(key, dim);
-                bool accept = false;
-                if (r1 >= 0.77f) {
-                    const float r2 = rt_rng_uniform(key, dim + 1);
-                    const float radius = __builtin_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1));
-                    const float m = fmaxf(fabsf(radius * __builtin_amdgcn_cosf(r2)), fabsf(radius * __builtin_amdgcn_sinf(r2)));
-                    if (m < 0.4999f) {
-                        accept = true;
-                    } else if (!(m > 0.5001f)) {
-                        float dx, dy;
-                        jitter_exact(key, dim, dx, dy);
-                        accept = !(fabsf(dx) > 0.5f || fabsf(dy) > 0.5f);
-                    }
-                }
-                if (accept) {
+                if (jitter_accepted<M>(key, dim)) {
                     accepted[r][threadIdx.x] = dim;
                     r++;
                     dim = 0;
@@ -590,15 +634,15 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
             float dx = 0.f, dy = 0.f;
             if (f.antialiasing) {
                 dim = accepted[r][threadIdx.x];
-                jitter_exact(rng, dim, dx, dy);
+                jitter_m<M>(rng, dim, dx, dy);
                 dim += 2;
             }
             const float fpx = (float)ux + 0.5f + dx;
             const float fpy = (float)uy + 0.5f + dy;
-            const V3 dir = normalize(mk((fpx - f.cx) / f.fx, (fpy - f.cy) / f.fy, 1.f));
-            V3 ray = mk(dot(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
-                        dot(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
-                        dot(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
+            const V3 dir = normalize_m<M>(mk(div_m<M>(fpx - f.cx, f.fx), div_m<M>(fpy - f.cy, f.fy), 1.f));
+            V3 ray = mk(dot_m<M>(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
+                        dot_m<M>(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
+                        dot_m<M>(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
             V3 start = eye;
             int sid = -1;
             float ts = INFINITY;
@@ -606,13 +650,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
                 const uint32_t cached = min(sc.n_spheres, kSphereCache);
                 for (uint32_t i = 0; i < cached; i++) {
                     const float4 e = eye_oc[i];
-                    sphere_step(dot(ray, xyz(e)), e.w, cache.sphere[i].w, i, ts, sid);
+                    sphere_step<M>(dot_m<M>(ray, xyz(e)), e.w, cache.sphere[i].w, i, ts, sid);
                 }
                 for (uint32_t i = cached; i < sc.n_spheres; i++) {
                     const float4 sph = sc.sphere[i];
                     const V3 oc = start - xyz(sph);
-                    const float ocn = norm(oc);
-                    sphere_step(dot(ray, oc), ocn * ocn, sph.w, i, ts, sid);
+                    sphere_step<M>(dot_m<M>(ray, oc), oc_norm2_m<M>(oc), sph.w, i, ts, sid);
                 }
             }
             n_casts += (uint32_t)__popcll(__ballot(!done));
@@ -628,10 +671,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
                 if (open && sid >= 0) {
                     float min_dist = INFINITY;
                     if (ts < min_dist) min_dist = ts;
-                    P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : start + min_dist * ray;
+                    P = isinf(min_dist) ? mk(INFINITY, INFINITY, INFINITY) : along_m<M>(start, min_dist, ray);
                     const int m = sphere_material(sc, cache, (uint32_t)sid);
-                    N = normalize(P - xyz(sphere_at(sc, cache, (uint32_t)sid)));
-                    respond_to_hit(sc, cache, f, rng, depth, m, P, N, start, ray, weight, colour, dim, flags, alive, lit, tinted);
+                    N = normalize_m<M>(P - xyz(sphere_at(sc, cache, (uint32_t)sid)));
+                    respond_to_hit<M>(sc, cache, f, rng, depth, m, P, N, start, ray, weight, colour, dim, flags, alive, lit, tinted);
                 }
                 // shadow rays of a diffuse hit and the bounce ray, as in k_shade
                 ts = INFINITY;
@@ -642,27 +685,44 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
                     const float4 li = light_at(sc, cache, l);
                     const V3 lp = xyz(li);
                     const V3 sp_ = lp - P;
-                    const float d = norm(sp_);
-                    const V3 wi = (1.f / d) * sp_;
-                    const float nwi = fmaxf(dot(N, wi), 0.f);
-                    const V3 sray = normalize(lp - start);
-                    const float dist = norm(lp - start);
+                    V3 wi, sray;
+                    float d, dist;
+                    if constexpr (M::kExact) {
+                        d = norm(sp_);
+                        wi = (1.f / d) * sp_;
+                        sray = normalize(lp - start);
+                        dist = norm(lp - start);
+                    } else {
+                        const float d2 = fast_dot(sp_, sp_), rd = __builtin_amdgcn_rsqf(d2);
+                        d = d2 * rd;
+                        wi = rd * sp_;
+                        const V3 ls = lp - start;
+                        const float l2 = fast_dot(ls, ls), rl = __builtin_amdgcn_rsqf(l2);
+                        dist = l2 * rl;
+                        sray = rl * ls;
+                    }
+                    const float nwi = fmaxf(dot_m<M>(N, wi), 0.f);
                     float ds = INFINITY;
                     int shadow_sid = -1;
                     if (l == 0) {
-                        nearest_sphere_pair(sc, cache, start, lit, sray, dist, ds, shadow_sid, alive, ray, ts, sid);
+                        nearest_sphere_pair<M>(sc, cache, start, lit, sray, dist, ds, shadow_sid, alive, ray, ts, sid);
                         bounce_probed = true;
                     } else if (lit) {
-                        ds = nearest_sphere_shadow(sc, cache, sray, start, dist, shadow_sid);
+                        ds = nearest_sphere_shadow<M>(sc, cache, sray, start, dist, shadow_sid);
                     }
                     if (lit) {
                         const bool blocked = ds < dist;
-                        const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
-                        const V3 direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
-                        L = L + weight * direct;
+                        if constexpr (M::kExact) {
+                            const double q = (double)li.w / (4 * M_PI * M_PI * (double)d * (double)d);
+                            const V3 direct = nwi * ((blocked ? 0.f : 1.f) * scale_d(q, colour));
+                            L = L + weight * direct;
+                        } else {
+                            const float q = li.w * __builtin_amdgcn_rcpf((float)(4 * M_PI * M_PI) * d * d);
+                            L = L + weight * ((blocked ? 0.f : nwi * q) * colour);
+                        }
                     }
                 }
-                if (!bounce_probed && alive) ts = nearest_sphere(sc, cache, ray, start, sid); // a scene without lights
+                if (!bounce_probed && alive) ts = nearest_sphere<M>(sc, cache, ray, start, sid); // a scene without lights
                 n_casts += (uint32_t)__popcll(__ballot(lit)) * sc.n_lights + (uint32_t)__popcll(__ballot(alive));
                 if (tinted) weight = weight * colour;
                 open = alive;

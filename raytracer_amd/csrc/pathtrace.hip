@@ -161,6 +161,7 @@ int check_frame(const rt_scene* scene, const rt_camera* cam, const rt_options* o
         return RT_ERR_INVALID;
     }
     if (opt->max_depth < 0 || opt->max_depth > 64) { rt_set_error("max_depth %d outside [0, 64]", opt->max_depth); return RT_ERR_INVALID; }
+    if (opt->arithmetic != 0 && opt->arithmetic != 1) { rt_set_error("arithmetic %d is neither 0 (exact) nor 1 (fast)", opt->arithmetic); return RT_ERR_INVALID; }
     return RT_OK;
 }
 
@@ -812,17 +813,18 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         }
         if (stats) HIP_TRY(hipMemsetAsync(w.cast_count, 0, cast_counts.size() * sizeof(uint32_t), stream));
         // paths per lane: as many as still leave 2 048 workgroups (8 per CU)
+        const bool fast = opt->arithmetic != 0;
         if (f.n_paths >= 2048u * kBlock * 4)
-            hipLaunchKernelGGL(k_generate<4>, dim3((f.n_paths + kBlock * 4 - 1) / (kBlock * 4)), block, 0, stream, s->d, w, f);
+            hipLaunchKernelGGL((fast ? k_generate<4, FastMath> : k_generate<4, ExactMath>), dim3((f.n_paths + kBlock * 4 - 1) / (kBlock * 4)), block, 0, stream, s->d, w, f);
         else if (f.n_paths >= 2048u * kBlock * 2)
-            hipLaunchKernelGGL(k_generate<2>, dim3((f.n_paths + kBlock * 2 - 1) / (kBlock * 2)), block, 0, stream, s->d, w, f);
+            hipLaunchKernelGGL((fast ? k_generate<2, FastMath> : k_generate<2, ExactMath>), dim3((f.n_paths + kBlock * 2 - 1) / (kBlock * 2)), block, 0, stream, s->d, w, f);
         else
-            hipLaunchKernelGGL(k_generate<1>, grid, block, 0, stream, s->d, w, f);
+            hipLaunchKernelGGL((fast ? k_generate<1, FastMath> : k_generate<1, ExactMath>), grid, block, 0, stream, s->d, w, f);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
             if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_shade, depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
+            hipLaunchKernelGGL((fast ? k_shade_fast : k_shade), depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
         }
@@ -885,6 +887,7 @@ int accumulate_spheres(rt_scene* s, const rt_camera* cam, const rt_options* opt,
     f.prune_zero_terms = opt->cluster_culling != 0;
     const uint32_t n_samples = sample_end - sample_begin;
     const uint64_t total_paths = (uint64_t)n_samples * (row_end - row_begin) * cam->width;
+    const bool fast = opt->arithmetic != 0;
     const bool deferred = !stats && opt->profile == 2; // marks for rt_profile_collect: here only the whole call is timed
     if (stats || deferred) {
         s->event_tags.clear();
@@ -916,7 +919,7 @@ int accumulate_spheres(rt_scene* s, const rt_camera* cam, const rt_options* opt,
         for (uint32_t first = 0; first < n_samples; first += per_launch) {
             const uint32_t n = std::min(per_launch, n_samples - first);
             f.sample_begin = sample_begin + first;
-            hipLaunchKernelGGL(k_trace_spheres, dim3((f.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
+            hipLaunchKernelGGL((fast ? k_trace_spheres<FastMath> : k_trace_spheres<ExactMath>), dim3((f.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
                                reinterpret_cast<float4*>(d_sum), (float4*)nullptr, cast_count);
             if ((rc = after_launch((uint64_t)n * f.n_pixels)) != RT_OK) return rc;
         }
@@ -932,7 +935,7 @@ int accumulate_spheres(rt_scene* s, const rt_camera* cam, const rt_options* opt,
             f.sample_begin = sample_begin + first;
             f.n_paths = n * f.n_pixels;
             const uint32_t lanes = f.n_pixels * ((n + kTraceGroup - 1) / kTraceGroup);
-            hipLaunchKernelGGL(k_trace_spheres, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
+            hipLaunchKernelGGL((fast ? k_trace_spheres<FastMath> : k_trace_spheres<ExactMath>), dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
                                reinterpret_cast<float4*>(d_sum), rad, cast_count);
             hipLaunchKernelGGL(k_accumulate, dim3((f.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, w, f,
                                reinterpret_cast<float4*>(d_sum));

@@ -478,6 +478,7 @@ rt_options options_from(const RenderSettings& s, size_t seed) {
     o.max_depth = s.max_ray_depth;
     o.seed = static_cast<uint32_t>(seed);
     o.cluster_culling = s.cluster_culling;
+    o.arithmetic = s.fast_arithmetic ? 1 : 0;
     return o;
 }
 
@@ -945,6 +946,7 @@ int rt_host_scene_set_options(rt_host_scene* s, const rt_options* opt) {
     s->scene.settings.bounding_box = opt->bounding_box != 0;
     s->scene.settings.max_ray_depth = opt->max_depth;
     s->scene.settings.cluster_culling = opt->cluster_culling != 0;
+    s->scene.settings.fast_arithmetic = opt->arithmetic != 0;
     return RT_OK;
 }
 

@@ -99,6 +99,9 @@ struct RenderSettings {
     // not in the reference: skip clusters of triangles whose bounds a ray misses
     // (false = the reference's exhaustive triangle scan)
     bool cluster_culling = true;
+    // not in the reference's source, but what its build does: fused multiply-adds and the hardware's reciprocal,
+    // square-root and log / sin / cos instructions instead of the bit-exact restatement (rt_options.arithmetic = 1)
+    bool fast_arithmetic = false;
     // not in the reference: split every frame over HIP devices 0 .. devices-1 of this node
     // (samples per pixel first, bands of rows beyond that; sums exchanged over RCCL or peer copies)
     unsigned devices = 1;

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--out", default=None)
     ap.add_argument("--c5-spp", type=int, default=1000)
+    ap.add_argument("--arithmetic", type=int, default=0, help="rt_options.arithmetic: 0 exact, 1 fast")
+    ap.add_argument("--no-exhaustive", action="store_true", help="skip the rows with cluster culling off")
+    ap.add_argument("--only", default="", help="only rows whose name contains this")
     args = ap.parse_args()
 
     import raytracer_amd as rt
@@ -57,15 +60,17 @@ def main():
     ]
     results = []
     for name, ref_s, make, mode in rows:
+        if args.only and args.only not in name:
+            continue
         s = make()
         desc, cam = s.describe()
         dev = s.upload()
         paths = cam.width * cam.height * cam.num_rays
         frames = args.frames if paths < 1e9 else 1
         for culling in (True, False):
-            if culling is False and desc.n_triangles == 0:
+            if culling is False and (desc.n_triangles == 0 or args.no_exhaustive):
                 continue
-            opt = rt.make_options(*mode, seed=1, profile=False, cluster_culling=culling)
+            opt = rt.make_options(*mode, seed=1, profile=False, cluster_culling=culling, arithmetic=args.arithmetic)
             dev.render(cam, opt)
             dev_ms, e2e_ms, st = [], [], None
             for _ in range(frames):
@@ -75,7 +80,7 @@ def main():
                 dev_ms.append(st.gpu_ms)
             d, e = float(np.median(dev_ms)), float(np.median(e2e_ms))
             r = {
-                "row": name, "cluster_culling": culling, "width": cam.width, "height": cam.height, "spp": cam.num_rays,
+                "row": name, "cluster_culling": culling, "arithmetic": args.arithmetic, "width": cam.width, "height": cam.height, "spp": cam.num_rays,
                 "device_ms": d, "end_to_end_ms": e, "paths": int(st.paths), "mpaths_per_s": st.paths / d / 1e3,
                 "triangle_tests_per_path": st.triangle_tests / max(st.paths, 1),
                 "reference_gtx1050_s": ref_s, "speedup_vs_reference": (ref_s * 1e3 / d) if ref_s else None,
