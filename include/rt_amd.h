@@ -221,7 +221,9 @@ int rt_device_group_free(rt_device_group* group);
  * is rendered in more, smaller batches -- a few ten thousand paths each; the
  * sums are the ones rt_accumulate produces, bit for bit.  The call issues no
  * hipMalloc / hipFree and only enqueues work on `stream`; it takes no
- * statistics and reports no progress.  RT_ERR_INVALID when a single image row
+ * statistics, reports no progress and ignores rt_options.profile (timing marks
+ * need events, whose creation allocates).  RT_ERR_INVALID when the current
+ * device is not the one the scene was uploaded to.  RT_ERR_INVALID when a single image row
  * of the frame does not fit the array (several hundred thousand pixels wide,
  * or a scene with very many lights or clusters).  Call rt_init on the device
  * first (it resolves the array's address there; otherwise the first call

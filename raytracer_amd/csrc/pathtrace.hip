@@ -83,6 +83,7 @@ struct WorkSet {
 
 struct rt_scene {
     DeviceScene d{};
+    int device = -1;                     // the HIP device the scene was uploaded to
     std::vector<void*> allocations;
     // batch work buffers, grown on demand
     WorkSet ws{};
@@ -423,9 +424,11 @@ extern "C" int rt_init(int32_t device) {
     HIP_TRY(hipGetDeviceCount(&count));
     if (device < 0 || device >= count) { rt_set_error("rt_init: device %d of %d", device, count); return RT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(device));
-    // set-up time: resolve this device's copy of the static work area (rt_accumulate_static)
+    // set-up time: resolve this device's copy of the static work area, so that rt_accumulate_static finds it.
+    // A failure here is not rt_init's: it is reported by rt_accumulate_static, the only call that needs the area.
     unsigned char* area = nullptr;
-    return static_work_area(&area);
+    if (static_work_area(&area) != RT_OK) g_error[0] = '\0';
+    return RT_OK;
 }
 
 extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
@@ -664,6 +667,7 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
         light[i] = make_float4(d->light_pos[3 * i], d->light_pos[3 * i + 1], d->light_pos[3 * i + 2], d->light_intensity[i]);
 
     rt_scene* s = new rt_scene();
+    if (hipGetDevice(&s->device) != hipSuccess) s->device = -1;
     s->d.n_spheres = d->n_spheres;
     s->d.n_triangles = d->n_triangles;
     s->d.n_boxes = d->n_boxes;
@@ -1019,9 +1023,19 @@ extern "C" int rt_accumulate_static(rt_scene* s, const rt_camera* cam, const rt_
     int rc = check_accumulate(s, cam, opt, sample_begin, sample_end, 0, cam ? cam->height : 0, d_sum);
     if (rc != RT_OK) return rc;
     if (cam->height == 0 || sample_end == sample_begin) return RT_OK;
+    // Timing marks (rt_options.profile) need events, and creating an event allocates: this call takes none.
+    rt_options quiet = *opt;
+    quiet.profile = 0;
+    opt = &quiet;
     if (s->d.n_triangles == 0) // no mesh: the paths live in registers and need no work area at all
         return accumulate_spheres(s, cam, opt, sample_begin, sample_end, 0, cam->height, d_sum, static_cast<hipStream_t>(stream_),
                                   nullptr, nullptr, nullptr, false);
+    int device = -1;
+    HIP_TRY(hipGetDevice(&device));
+    if (device != s->device) { // the area is the current device's copy; the scene's arrays live where it was uploaded
+        rt_set_error("rt_accumulate_static: the scene lives on device %d, the current device is %d", s->device, device);
+        return RT_ERR_INVALID;
+    }
     unsigned char* area = nullptr;
     if ((rc = static_work_area(&area)) != RT_OK) return rc;
     // The largest batch whose work buffers fit the area (at most half of it for cluster lists): the

@@ -13,6 +13,7 @@ _hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
 _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 _hip.hipDeviceSynchronize.argtypes = []
 _hip.hipGetDeviceCount.argtypes = [C.POINTER(C.c_int)]
+_hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
 
 
 def _ok(code, what):
@@ -69,3 +70,38 @@ def free_bytes():
     _hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     _ok(_hip.hipMemGetInfo(C.byref(free), C.byref(total)), "hipMemGetInfo")
     return free.value
+
+
+class CapturedGraph:
+    """Work captured from a stream into a HIP graph (hipStreamBeginCapture .. hipStreamEndCapture) and replayed."""
+
+    def __init__(self):
+        self.stream = C.c_void_p()
+        _ok(_hip.hipStreamCreate(C.byref(self.stream)), "hipStreamCreate")
+        self.graph, self.executable = C.c_void_p(), C.c_void_p()
+
+    def begin(self):
+        _hip.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+        _ok(_hip.hipStreamBeginCapture(self.stream, 0), "hipStreamBeginCapture")  # hipStreamCaptureModeGlobal
+
+    def end(self):
+        _hip.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        _ok(_hip.hipStreamEndCapture(self.stream, C.byref(self.graph)), "hipStreamEndCapture")
+        _hip.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        _ok(_hip.hipGraphInstantiate(C.byref(self.executable), self.graph, None, None, 0), "hipGraphInstantiate")
+
+    def launch(self):
+        _hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+        _hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        _ok(_hip.hipGraphLaunch(self.executable, self.stream), "hipGraphLaunch")
+        _ok(_hip.hipStreamSynchronize(self.stream), "hipStreamSynchronize")
+
+    def free(self):
+        _hip.hipGraphExecDestroy.argtypes = [C.c_void_p]
+        _hip.hipGraphDestroy.argtypes = [C.c_void_p]
+        _hip.hipStreamDestroy.argtypes = [C.c_void_p]
+        if self.executable:
+            _hip.hipGraphExecDestroy(self.executable)
+        if self.graph:
+            _hip.hipGraphDestroy(self.graph)
+        _hip.hipStreamDestroy(self.stream)

@@ -11,24 +11,33 @@ import pytest
 
 import raytracer_amd as rt
 from helpers import load, variant
-from hip_mem import DeviceBuffer
+from hip_mem import CapturedGraph, DeviceBuffer, free_bytes
 
 pytestmark = pytest.mark.gpu
 
 
-def accumulate_static(dev, cam, opt, begin, end, buf):
-    return rt.lib.rt_accumulate_static(dev._h, C.byref(cam), C.byref(opt), begin, end, C.c_void_p(buf.address), None)
+def accumulate_static(dev, cam, opt, begin, end, buf, stream=None):
+    return rt.lib.rt_accumulate_static(dev._h, C.byref(cam), C.byref(opt), begin, end, C.c_void_p(buf.address), stream)
 
 
 def both_ways(scene, opt, begin, end):
+    """rt_accumulate_static on a FRESH scene handle -- no rt_accumulate has given it work buffers -- with the free
+    device memory read before and after the call, then rt_accumulate on a second handle of the same scene."""
     desc, cam = scene.describe()
     dev = scene.upload()
     n = cam.width * cam.height
     want, got = DeviceBuffer(4 * n), DeviceBuffer(4 * n)
-    dev.accumulate(cam, opt, begin, end, want.address)
+    # one warm-up call on another fresh handle: the runtime loads a kernel's code when it is first launched
+    assert accumulate_static(scene.upload(), cam, opt, begin, end, got) == rt.RT_OK, rt.lib.rt_last_error()
+    got.to_host()  # (synchronises: nothing of the set-up is still in flight)
+    got.zero()
+    before = free_bytes()
     rc = accumulate_static(dev, cam, opt, begin, end, got)
     assert rc == rt.RT_OK, rt.lib.rt_last_error()
-    a, b = want.to_host(), got.to_host()
+    b = got.to_host()
+    assert free_bytes() == before, f"rt_accumulate_static changed the free device memory by {before - free_bytes()} bytes"
+    scene.upload().accumulate(cam, opt, begin, end, want.address)
+    a = want.to_host()
     assert a.reshape(-1, 4)[:, 3].max() == end - begin
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).reshape(-1, 4).any(axis=1).sum()} of {n} pixels differ"
     return dev, cam, got
@@ -54,6 +63,52 @@ def test_static_work_area_gives_the_sums_of_rt_accumulate():
     assert accumulate_static(dev, cam, opt, 0, 2, parts) == rt.RT_OK
     assert accumulate_static(dev, cam, opt, 2, 5, parts) == rt.RT_OK
     assert np.array_equal(whole.to_host().view(np.uint32), parts.to_host().view(np.uint32))
+
+
+def test_static_work_area_ignores_the_profile_option():
+    """Timing marks would create events (an allocation): the call takes none, whatever rt_options.profile says."""
+    rt.init(0)
+    s = load("mesh_scene", 64, 48, 2)
+    desc, cam = s.describe()
+    dev = s.upload()
+    n = cam.width * cam.height
+    plain, marked = DeviceBuffer(4 * n), DeviceBuffer(4 * n)
+    assert accumulate_static(dev, cam, rt.make_options(seed=66), 0, 2, plain) == rt.RT_OK
+    plain.to_host()
+    before = free_bytes()
+    assert accumulate_static(dev, cam, rt.make_options(seed=66, profile=2), 0, 2, marked) == rt.RT_OK
+    assert np.array_equal(plain.to_host().view(np.uint32), marked.to_host().view(np.uint32))
+    assert free_bytes() == before
+    with pytest.raises(rt.RtError):  # no marks were left for rt_profile_collect
+        dev.profile_collect()
+
+
+def test_static_work_area_under_stream_capture():
+    """The callers the entry point is for: the call is captured into a HIP graph (nothing runs, nothing may be
+    allocated while a stream captures) and the graph replayed twice; the sums are rt_accumulate's."""
+    rt.init(0)
+    s = load("mesh_scene", 96, 64, 3)
+    desc, cam = s.describe()
+    dev = s.upload()
+    n = cam.width * cam.height
+    opt = rt.make_options(seed=67)
+    want, got = DeviceBuffer(4 * n), DeviceBuffer(4 * n)
+    scene2 = s.upload()
+    scene2.accumulate(cam, opt, 0, 3, want.address)
+    a = want.to_host()
+    g = CapturedGraph()
+    try:
+        g.begin()
+        rc = accumulate_static(dev, cam, opt, 0, 3, got, g.stream)
+        g.end()
+        assert rc == rt.RT_OK, rt.lib.rt_last_error()
+        assert not got.to_host().any()  # captured, not run
+        for _ in range(2):
+            got.zero()
+            g.launch()
+            assert np.array_equal(got.to_host().view(np.uint32), a.view(np.uint32))
+    finally:
+        g.free()
 
 
 def test_static_work_area_rejects_what_does_not_fit():

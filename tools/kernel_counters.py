@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Per-kernel hardware-counter figures for bench.py's roofline objects, from the passes of tools/pmc_passes.sh:
 
-    python tools/kernel_counters.py <pmc dir> <config> <summary file name under profiles/>   ->   profiles/kernel_counters.json
+    python tools/kernel_counters.py <config> <summary file name under profiles/> <pmc dir>[:kernel,kernel...] ...   ->   profiles/kernel_counters.json
+
+(a directory may be restricted to some kernels: the exhaustive-scan frames of a run also launch the path kernels, with
+more live paths than the default mode has, so k_mesh is taken from a run with those frames and the rest from one without)
 
 Per kernel (mean over its dispatches in the profiled run): VALU wave-instructions per launch (SQ_INSTS_VALU) and HBM
 bytes per launch = FETCH_SIZE x correction + WRITE_SIZE (both in KB).  On gfx950 FETCH_SIZE tallies a wide coalesced
@@ -34,14 +37,17 @@ def short(name):
 
 
 def main():
-    root, config, source = sys.argv[1], sys.argv[2], sys.argv[3]
+    config, source = sys.argv[1], sys.argv[2]
     acc = defaultdict(lambda: defaultdict(list))
-    for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
-        with open(path) as f:
-            for row in csv.DictReader(f):
-                name = kernel_name(row["Kernel_Name"])
-                if name.startswith("k_"):
-                    acc[short(name)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for spec in sys.argv[3:]:
+        root, _, only = spec.partition(":")
+        only = set(only.split(",")) if only else None
+        for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    name = kernel_name(row["Kernel_Name"])
+                    if name.startswith("k_") and (only is None or short(name) in only):
+                        acc[short(name)][row["Counter_Name"]].append(float(row["Counter_Value"]))
     out = {}
     for k, counters in sorted(acc.items()):
         if not all(c in counters for c in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE")):
