@@ -7,7 +7,7 @@ f = sorted(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 names = [(r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:34], int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows]
-starts = [i for i, n in enumerate(names) if n[0].startswith('k_generate') and i + 1 < len(names) and names[i + 1][0].startswith(('k_bin', 'k_group', 'k_mesh'))]
+starts = [i for i, n in enumerate(names) if n[0].startswith('k_generate') and i + 1 < len(names) and names[i + 1][0].startswith(('k_bin', 'k_group', 'k_mesh', 'k_mark'))]
 s = starts[-back]
 prev = None
 total = 0.0
