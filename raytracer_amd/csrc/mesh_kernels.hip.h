@@ -395,14 +395,29 @@ __device__ __forceinline__ SlabRay slab_ray(float4 o4, float4 d4) {
 // of the test, or 0 * inf) are dropped by the minimum / maximum: that axis does
 // not constrain the ray, which errs towards "touches".  The box
 // data of an iteration (scalar loads) serves all R rays.
+// Bounds of a pair of boxes: lo.x lo.y lo.z hi.x hi.y hi.z, each as (box 2k, box 2k+1).
+struct BoxPair {
+    f2 v[6];
+};
+
+__device__ __forceinline__ BoxPair load_box_pair(const f2* __restrict__ box_pair, uint32_t k) {
+    BoxPair p;
+    const f2* __restrict__ g = box_pair + 6 * (size_t)k;
+#pragma unroll
+    for (int i = 0; i < 6; i++) p.v[i] = g[i];
+    return p;
+}
+
 template <int R>
 __device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint32_t first, uint32_t last, const SlabRay (&ray)[R],
                                           uint32_t (&bits)[R]) {
 #pragma unroll
     for (int i = 0; i < R; i++) bits[i] = 0;
-    for (uint32_t k = first; k < last; k++) {
-        const f2* __restrict__ b = box_pair + 6 * (size_t)k;
-        const f2 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
+    if (first >= last) return;
+    // The box data arrives by scalar loads, whose only wait is "all of them": the next pair is requested right after
+    // that wait and before the current pair is tested, so that a load is in flight during every test (as in scan_pairs).
+    auto test = [&](const BoxPair& p) {
+        const f2 b0 = p.v[0], b1 = p.v[1], b2 = p.v[2], b3 = p.v[3], b4 = p.v[4], b5 = p.v[5];
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const SlabRay& r = ray[i];
@@ -420,11 +435,23 @@ __device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint3
                 "v_cmp_ge_f32 vcc, %3, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                 : "+v"(bits[i]) : "v"(out0), "v"(in0), "v"(out1), "v"(in1) : "vcc");
         }
+    };
+    // two pairs per trip, two register sets: each set is requested right after a wait and just before the OTHER set is tested
+    BoxPair cur = load_box_pair(box_pair, first);
+    for (uint32_t k = first; k < last; k += 2) {
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): `cur` has landed
+        const BoxPair nxt = load_box_pair(box_pair, min(k + 1, last - 1));
+        __builtin_amdgcn_sched_barrier(0); // keep the request ahead of the tests it overlaps
+        test(cur);
+        __builtin_amdgcn_s_waitcnt(0xC07F); // `nxt` has landed
+        cur = load_box_pair(box_pair, min(k + 2, last - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < last) test(nxt);
     }
     // box 2 (k - first) + h to bit 2 (k - first) + h
     const uint32_t used = 2 * (last - first);
 #pragma unroll
-    for (int i = 0; i < R; i++) bits[i] = used ? __brev(bits[i]) >> (32 - used) : 0u;
+    for (int i = 0; i < R; i++) bits[i] = __brev(bits[i]) >> (32 - used);
 }
 
 // The boxes (up to 64, as a bit mask) that S rays per lane enter before their
