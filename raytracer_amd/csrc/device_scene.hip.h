@@ -100,12 +100,6 @@ struct Work {
     uint32_t* grp_count;     // the same three for the groups of clusters
     uint32_t* grp_list;
     uint32_t list_capacity;  // = rays binned per tile
-    // meshes whose second level lives in LDS (DeviceScene::fused_groups) keep marks instead of lists: per group a bit
-    // per queue position (n_groups bit maps of bits_stride 64-bit words, reused by every stage), and per stage the
-    // counter the workgroups of k_group_clusters draw their pieces from
-    unsigned long long* grp_bits;
-    uint32_t bits_stride;
-    uint32_t* piece_count;
     // the paths that are still alive, for the next bounce: kShards shards like the ray queue,
     // two buffers (bounce d reads buffer d & 1 and fills the other)
     uint32_t* live;

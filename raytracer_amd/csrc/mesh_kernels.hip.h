@@ -669,20 +669,24 @@ __global__ __launch_bounds__(kBlock) void k_mark_groups(const f2* __restrict__ g
     if (threadIdx.x < n_groups && total_s[threadIdx.x]) atomicAdd(&grp_count[threadIdx.x * kCountStride], total_s[threadIdx.x]);
 }
 
-// A lane's hit is final for that (ray, pair): it goes to the ray's slot with the 64-bit atomic
-// minimum on (t bits, caller's triangle index) that merges chunks and clusters anyway.  The exact
-// quotient of an accepted hit is deferred (`pend`): a lane flushes it when its next hit arrives
-// or the pass ends, so the division and the atomic run about once per pass, not once per trip.
+// A lane's hit is final for that (ray, pair).  The hits of a run's rays are merged in LDS with the 64-bit minimum on
+// (t bits, caller's triangle index) -- the reference's "nearest, first triangle wins ties" whatever the order of
+// arrival -- and every ray that was hit goes to its slot in memory once, after the scan, with the atomic minimum that
+// merges runs, clusters and chunks anyway.  (No store or atomic to memory inside the scan: on this hardware loads and
+// stores complete out of order with respect to each other and share one counter, so a pending store turns every wait
+// for a load into a wait for everything, which would defeat the prefetch of the next cluster's triangles.)
+// The exact quotient of an accepted hit is deferred (`pend`): a lane flushes it when its next hit arrives or the run
+// ends, so the divisions of several trips' hits run together.
 struct PendingHit {
     float num, den;
     uint32_t orig;   // caller's index of the triangle; 0xffffffff: none pending
-    uint32_t slot;
+    uint32_t entry;  // the ray's entry number in the run
 };
 
-__device__ __forceinline__ void flush_hit(PendingHit& pend, unsigned long long* __restrict__ hit) {
+__device__ __forceinline__ void flush_hit(PendingHit& pend, unsigned long long* best) {
     if (pend.orig != 0xffffffffu) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(pend.num / pend.den) << 32) | pend.orig;
-        atomicMin(&hit[pend.slot], key);
+        atomicMin(&best[pend.entry], key);
         pend.orig = 0xffffffffu;
     }
 }
@@ -697,260 +701,176 @@ __device__ __forceinline__ uint32_t scan16(uint32_t v, uint32_t lane) {
     return v;
 }
 
-// A pass of a piece has four phases, separated by barriers:
+// Orders this wavefront's LDS traffic: what its lanes wrote before is visible to all of its lanes after.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Second level and triangle scan for meshes of up to kFusedMaxGroups * kFusedGroup clusters, one WAVEFRONT at a time:
+// a wavefront takes a run of 64 * E entries of one group's list and, on its own, without a workgroup barrier,
 //
-//   expand   the lanes that hold bit-map words write the queue positions of the set bits that fall
-//            into this pass (the words' set bits are numbered through the piece by a prefix sum);
-//   bin      every lane fetches R rays, keeps them in LDS (32 bytes each), tests them against the
-//            group's cluster boxes and counts per cluster (its 16-bit masks stay in registers);
-//   scatter  the counts give every cluster a segment of one pool of references (2 * kPass 16-bit
-//            entry numbers -- if the pass needs more, the clusters are taken in several rounds);
-//            every lane drops its entries into the segments of the clusters they touch;
-//   scan     the wavefronts draw (cluster, 64 references) units from a counter and work as 8
-//            triangle pairs x 8 rays: a lane keeps ONE pair of the cluster in registers for the whole
-//            unit (clusters of more than 8 pairs: one chunk of 8 after the other) and meets a new ray,
-//            read from LDS, every trip -- 128 ray-triangle tests per trip, the packed arithmetic of
-//            k_mesh.  With clusters of 8 pairs the group's triangle pairs are staged in LDS once per
-//            piece (kTriLds), so that a unit starts without a round trip to memory.
+//   bins     every lane fetches E rays, keeps them in LDS (32 bytes each), tests them against the group's
+//            cluster boxes and counts per cluster (the 16-bit masks stay in registers);
+//   scatters the counts give every cluster a segment of a pool of references (2 * 64 * E entry numbers; if
+//            the run needs more, the clusters are taken in several rounds), and every lane drops its
+//            entries into the segments of the clusters they touch;
+//   scans    cluster after cluster as 8 triangle pairs x 8 rays: a lane keeps ONE pair of the cluster in
+//            registers (clusters of more than 8 pairs: one chunk of 8 after the other) and meets a new ray,
+//            read from LDS, every trip -- 128 ray-triangle tests per trip, the packed arithmetic of k_mesh.
+//            The first pairs of the next cluster are requested before the current one is scanned.
 //
-// Compared with a lane per ray and a wave-uniform triangle (k_mesh, where thousands of rays share
-// one long triangle stream): no chain of dependent scalar loads per unit, rays come in eights
-// instead of sixty-fours, and the rays are read from memory once per pass.
-template <int T, bool kTriLds>
-__global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
-                                                      uint32_t n_clusters, uint32_t cluster_pairs, uint32_t n_groups,
-                                                      uint32_t group_clusters, const f2* __restrict__ cl_pair,
-                                                      const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                      const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
-                                                      const unsigned long long* __restrict__ grp_bits, uint32_t bits_stride,
-                                                      const uint32_t* __restrict__ grp_count, uint32_t piece_entries,
-                                                      uint32_t* __restrict__ piece_counter, unsigned long long* __restrict__ hit,
-                                                      uint32_t* __restrict__ cl_stat) {
-    constexpr int R = 2;                                 // rays per lane and pass
-    constexpr uint32_t kPass = R * T;                    // entries per pass
-    constexpr uint32_t kWaves = T / 64;
-    constexpr uint32_t kPool = 2 * kPass;                // references per round
-    constexpr uint32_t kGroupPairs = kFusedGroup * kClusterPairs;
-    static_assert(kPass <= 65536 && T >= 64 && T % 64 == 0 && kFusedGroup == 16, "entry numbers are 16 bits wide; scan16 covers a group's clusters");
-    __shared__ float4 ray_s[2 * kPass];                  // this pass's rays: origin + hit slot, direction + cut-off
-    __shared__ uint32_t pos_s[kPass];                    // queue position of each entry
-    __shared__ uint16_t refs_s[kPool];                   // entry numbers, one segment per cluster
-    __shared__ float4 tri_s[kTriLds ? 6 * kGroupPairs : 1]; // the group's triangle pairs (12 float2 each)
-    __shared__ uint32_t orig_s[kTriLds ? 2 * kGroupPairs : 2];
-    __shared__ uint32_t before_s[kShards + 1];           // bit-map words of the shards before each shard
-    __shared__ uint32_t first_piece[kFusedMaxGroups + 1]; // pieces of the groups before each group
-    __shared__ uint32_t pieces_s[kFusedMaxGroups];       // pieces of each group
-    __shared__ uint32_t cl_cnt[kFusedGroup], cl_fill[kFusedGroup], base_s[kWaves][kFusedGroup];
-    __shared__ uint32_t wave_tot[kWaves];
-    __shared__ uint32_t piece_s, next_unit;
+// (First version: a workgroup of 512 threads per 1 024 entries, phases separated by barriers: its wavefronts
+// spent a third of the time waiting for each other and for the phase's memory accesses, and every launch
+// took 25-45 us however short the lists.)
+template <int E>
+__global__ __launch_bounds__(kBlock) void k_group_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
+                                                           uint32_t n_clusters, uint32_t cluster_pairs, uint32_t n_groups,
+                                                           uint32_t group_clusters, const f2* __restrict__ cl_pair,
+                                                           const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                           const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_list,
+                                                           uint32_t list_capacity, unsigned long long* __restrict__ hit,
+                                                           uint32_t* __restrict__ cl_stat) {
+    constexpr uint32_t kRun = 64 * E;                    // entries per run
+    constexpr uint32_t kPool = 2 * kRun;                 // references per round
+    static_assert(kRun <= 256 && kFusedGroup == 16, "entry numbers are 8 bits wide; scan16 covers a group's clusters");
+    __shared__ float4 ray_s[kWavesPerBlock][2 * kRun];   // the run's rays: origin + hit slot, direction + cut-off
+    __shared__ uint8_t refs_s[kWavesPerBlock][kPool];    // entry numbers, one segment per cluster
+    __shared__ unsigned long long best_s[kWavesPerBlock][kRun]; // nearest hit of each of the run's rays so far
+    __shared__ uint32_t cnt_s[kWavesPerBlock][kFusedGroup], fill_s[kWavesPerBlock][kFusedGroup], base_s[kWavesPerBlock][kFusedGroup];
+    __shared__ uint32_t first_run[kFusedMaxGroups + 1];  // runs of the groups before each group
 
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    // ---- plan (every workgroup computes the same one): words per shard; per group, words per piece
-    // such that a piece holds about piece_entries marked rays, and the number of pieces
-    if (wave == 0) {
-        const uint32_t words = (q_count[lane * kCountStride] + 63u) / 64u;
-        uint32_t incl = words;
+    if (wave == 0) { // the plan, the same in every workgroup
+        const uint32_t mine = lane < n_groups ? grp_count[lane * kCountStride] : 0;
+        const uint32_t runs = (mine + kRun - 1) / kRun;
+        uint32_t incl = runs;
 #pragma unroll
         for (int step = 1; step < 64; step <<= 1) {
             const uint32_t up = __shfl_up(incl, step);
             if ((int)lane >= step) incl += up;
         }
-        before_s[lane] = incl - words;
-        const uint32_t total_words = __shfl(incl, 63);
-        if (lane == 63) before_s[kShards] = incl;
-        const uint32_t marked = lane < n_groups ? grp_count[lane * kCountStride] : 0;
-        uint32_t per_piece = 0, pieces = 0;
-        if (marked) {
-            // words that hold piece_entries marked rays at this group's density, at least 64 and at most T (a word per lane)
-            const unsigned long long want = ((unsigned long long)piece_entries * total_words + marked - 1) / marked;
-            per_piece = (uint32_t)(want < 64 ? 64 : want > (unsigned long long)T ? (unsigned long long)T : want);
-            pieces = (total_words + per_piece - 1) / per_piece; // (so that pieces * T >= total_words: a word per lane covers the map)
-        }
-        uint32_t pincl = pieces;
-#pragma unroll
-        for (int step = 1; step < 64; step <<= 1) {
-            const uint32_t up = __shfl_up(pincl, step);
-            if ((int)lane >= step) pincl += up;
-        }
-        if (lane < n_groups) { first_piece[lane] = pincl - pieces; pieces_s[lane] = pieces; }
-        if (lane == 63) first_piece[n_groups] = pincl; // lanes past n_groups add nothing: the total
+        if (lane < n_groups) first_run[lane] = incl - runs;
+        if (lane == 63) first_run[n_groups] = incl; // lanes past n_groups add nothing: the total
     }
     __syncthreads();
-    const uint32_t total_words = before_s[kShards], n_pieces = first_piece[n_groups];
+    const uint32_t n_runs = first_run[n_groups];
     const uint32_t n_pairs = (n_tri + 1) / 2;
     const uint32_t my_pair = lane & 7u, my_ray = lane >> 3;
+    float4* __restrict__ rays = ray_s[wave];
+    uint8_t* __restrict__ refs = refs_s[wave];
+    uint32_t* __restrict__ cnt = cnt_s[wave];
+    uint32_t* __restrict__ fill = fill_s[wave];
+    uint32_t* __restrict__ base = base_s[wave];
+    unsigned long long* __restrict__ best = best_s[wave];
 
-    for (;;) {
-        if (threadIdx.x == 0) piece_s = atomicAdd(piece_counter, 1u);
-        __syncthreads();
-        const uint32_t piece = piece_s;
-        if (piece >= n_pieces) break;
-        // the group this piece belongs to (first_piece is non-decreasing; n_groups <= 64: one ballot; groups without
-        // pieces share their successor's value and the last of the candidates is the one that holds the piece)
-        const uint32_t fp = lane < n_groups ? first_piece[lane] : 0xffffffffu;
-        const uint32_t g = (uint32_t)__popcll(__ballot(fp <= piece)) - 1u;
-        // A piece takes every pieces-th word of the group's bit map: the queue follows the image (a shard holds the rays
-        // of every 64th wavefront of the path kernel, in path order), and a group's rays come from one part of the image,
-        // so ranges of consecutive words would differ in their number of set bits many times over.
-        const uint32_t pieces = pieces_s[g];
+    for (uint32_t run = blockIdx.x * kWavesPerBlock + wave; run < n_runs; run += gridDim.x * kWavesPerBlock) {
+        // the group this run belongs to (first_run is non-decreasing; groups without runs share their successor's value)
+        const uint32_t fr = lane < n_groups ? first_run[lane] : 0xffffffffu;
+        const uint32_t g = (uint32_t)__popcll(__ballot(fr <= run)) - 1u;
+        const uint32_t count = grp_count[g * kCountStride];
+        const uint32_t run_begin = (run - first_run[g]) * kRun;
+        const uint32_t n_e = min(kRun, count - run_begin);
         const uint32_t first_cluster = g * group_clusters; // even: a group starts a box pair
         const uint32_t boxes = min(group_clusters, n_clusters - first_cluster);
         const uint32_t real = (1u << boxes) - 1u;          // an odd count leaves half a box pair without a box
-        const uint32_t group_first_pair = first_cluster * cluster_pairs;
+        const uint32_t* __restrict__ my_list = grp_list + (size_t)g * list_capacity + run_begin;
 
-        // ---- this lane's word of the group's bit map, its set bits numbered through the piece
-        unsigned long long bits = 0;
-        uint32_t first_pos = 0; // queue position of the word's bit 0
-        {
-            const uint32_t wi = (piece - first_piece[g]) + threadIdx.x * pieces;
-            if (wi < total_words) {
-                uint32_t lo = 0, hi = kShards; // last shard with before_s[shard] <= wi (empty shards share their successor's value)
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (before_s[mid] <= wi) lo = mid; else hi = mid;
+        // ---- bin
+        if (lane < kFusedGroup) { cnt[lane] = 0; fill[lane] = 0; }
+        SlabRay ray[E];
+        bool active[E];
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const uint32_t e = i * 64 + lane;
+            active[i] = e < n_e;
+            const uint32_t pos = my_list[active[i] ? e : n_e - 1];
+            const float4 o4 = q_o[2 * (size_t)pos], d4 = q_d[2 * (size_t)pos];
+            rays[2 * e] = o4;
+            rays[2 * e + 1] = d4;
+            best[e] = kNoHit;
+            ray[i] = slab_ray(o4, d4);
+        }
+        uint32_t cmask[E];
+        slab_bits<E>(cl_pair + 6 * (size_t)(first_cluster / 2), 0, (boxes + 1) / 2, ray, cmask);
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            cmask[i] = active[i] ? (cmask[i] & real) : 0u;
+            for (uint32_t m = cmask[i]; m; m &= m - 1) atomicAdd(&cnt[(uint32_t)__ffs((int)m) - 1u], 1u);
+        }
+        wave_sync();
+
+        // ---- the clusters in rounds of at most kPool references (one round, unless the rays touch many clusters each)
+        const uint32_t mine_cnt = lane < boxes ? cnt[lane] : 0u;
+        const uint32_t cincl = scan16(mine_cnt, lane);
+        PendingHit pend;
+        pend.num = 0.f; pend.den = 1.f; pend.orig = 0xffffffffu; pend.entry = 0;
+        for (uint32_t c_lo = 0; c_lo < boxes;) {
+            const uint32_t before_round = __shfl(cincl - mine_cnt, (int)c_lo);
+            // (a cluster holds at most kRun <= kPool references: every round takes at least one cluster)
+            const unsigned long long over = __ballot(lane > c_lo && lane < boxes && cincl - before_round > kPool);
+            const uint32_t c_hi = over ? (uint32_t)__ffsll((long long)over) - 1u : boxes;
+            // ---- scatter
+            if (lane < kFusedGroup) { base[lane] = cincl - mine_cnt - before_round; if (c_lo > 0) fill[lane] = 0; }
+            wave_sync();
+            const uint32_t in_round = ((1u << c_hi) - 1u) & ~((1u << c_lo) - 1u);
+#pragma unroll
+            for (int i = 0; i < E; i++)
+                for (uint32_t m = cmask[i] & in_round; m; m &= m - 1) {
+                    const uint32_t c = (uint32_t)__ffs((int)m) - 1u;
+                    refs[base[c] + atomicAdd(&fill[c], 1u)] = (uint8_t)(i * 64 + lane);
                 }
-                const uint32_t qword = lo * (shard_capacity >> 6) + (wi - before_s[lo]);
-                bits = grp_bits[(size_t)g * bits_stride + qword];
-                first_pos = qword << 6;
-            }
-        }
-        const uint32_t cnt = (uint32_t)__popcll(bits);
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int step = 1; step < 64; step <<= 1) {
-            const uint32_t up = __shfl_up(incl, step);
-            if ((int)lane >= step) incl += up;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t off = incl - cnt, n = 0; // number of this lane's first set bit, set bits of the piece
-#pragma unroll
-        for (uint32_t v = 0; v < kWaves; v++) {
-            const uint32_t t = wave_tot[v];
-            if (v < wave) off += t;
-            n += t;
-        }
-        if constexpr (kTriLds) { // the group's triangle pairs and their callers' indices (read after the barriers of the first pass)
-            if (n) {
-                const uint32_t group_pairs = min(boxes * cluster_pairs, n_pairs - group_first_pair);
-                const float4* __restrict__ src = reinterpret_cast<const float4*>(tri2 + 12 * (size_t)group_first_pair);
-                for (uint32_t i = threadIdx.x; i < 6 * group_pairs; i += T) tri_s[i] = src[i];
-                for (uint32_t i = threadIdx.x; i < 2 * group_pairs; i += T) orig_s[i] = tri_orig[2 * (size_t)group_first_pair + i];
-            }
-        }
+            wave_sync();
 
-        for (uint32_t pass = 0; pass < n; pass += kPass) {
-            const uint32_t n_e = min(kPass, n - pass); // entries of this pass
-            // ---- expand
-            if (threadIdx.x < kFusedGroup) { cl_cnt[threadIdx.x] = 0; cl_fill[threadIdx.x] = 0; }
-            if (threadIdx.x == 0) next_unit = 0;
-            if (cnt && off < pass + kPass && off + cnt > pass) {
-                uint32_t i = off;
-                for (unsigned long long m = bits; m; m &= m - 1, i++)
-                    if (i >= pass && i < pass + kPass) pos_s[i - pass] = first_pos + (uint32_t)__ffsll((long long)m) - 1u;
-            }
-            __syncthreads();
-
-            // ---- bin: this pass's rays into LDS, their cluster masks beside them, counts per cluster
-            SlabRay ray[R];
-            bool active[R];
-#pragma unroll
-            for (int i = 0; i < R; i++) {
-                const uint32_t e = i * T + threadIdx.x;
-                active[i] = e < n_e;
-                const uint32_t pos = pos_s[active[i] ? e : 0];
-                const float4 o4 = q_o[2 * (size_t)pos], d4 = q_d[2 * (size_t)pos];
-                ray_s[2 * e] = o4;
-                ray_s[2 * e + 1] = d4;
-                ray[i] = slab_ray(o4, d4);
-            }
-            uint32_t cmask[R];
-            slab_bits<R>(cl_pair + 6 * (size_t)(first_cluster / 2), 0, (boxes + 1) / 2, ray, cmask);
-#pragma unroll
-            for (int i = 0; i < R; i++) {
-                cmask[i] = active[i] ? (cmask[i] & real) : 0u;
-                for (uint32_t m = cmask[i]; m; m &= m - 1) atomicAdd(&cl_cnt[(uint32_t)__ffs((int)m) - 1u], 1u);
-            }
-            __syncthreads();
-
-            // ---- the clusters in rounds of at most kPool references (one round, unless the rays touch many clusters each)
-            const uint32_t mine_cnt = lane < boxes ? cl_cnt[lane] : 0u;
-            const uint32_t cincl = scan16(mine_cnt, lane);
-            PendingHit pend;
-            pend.num = 0.f; pend.den = 1.f; pend.orig = 0xffffffffu; pend.slot = 0;
-            for (uint32_t c_lo = 0; c_lo < boxes;) {
-                const uint32_t before_round = __shfl(cincl - mine_cnt, (int)c_lo);
-                // (a cluster holds at most kPass <= kPool references: every round takes at least one cluster)
-                const unsigned long long over = __ballot(lane > c_lo && lane < boxes && cincl - before_round > kPool);
-                const uint32_t c_hi = over ? (uint32_t)__ffsll((long long)over) - 1u : boxes;
-                if (c_lo > 0) { // a later round: the counters of the last one are reused
-                    if (threadIdx.x < kFusedGroup) cl_fill[threadIdx.x] = 0;
-                    if (threadIdx.x == 0) next_unit = 0;
-                    __syncthreads();
-                }
-                // ---- scatter
-                if (lane < kFusedGroup) base_s[wave][lane] = cincl - mine_cnt - before_round;
-                const uint32_t in_round = ((1u << c_hi) - 1u) & ~((1u << c_lo) - 1u);
-#pragma unroll
-                for (int i = 0; i < R; i++)
-                    for (uint32_t m = cmask[i] & in_round; m; m &= m - 1) {
-                        const uint32_t c = (uint32_t)__ffs((int)m) - 1u;
-                        refs_s[base_s[wave][c] + atomicAdd(&cl_fill[c], 1u)] = (uint16_t)(i * T + threadIdx.x);
+            // ---- scan: the clusters of this round that hold references, one after the other
+            unsigned long long todo = __ballot(lane >= c_lo && lane < c_hi && mine_cnt > 0);
+            auto fetch = [&](uint32_t c, uint32_t chunk, PairData& pd, uint2& orig) {
+                const uint32_t first = (first_cluster + c) * cluster_pairs;
+                const uint32_t last = min(first + cluster_pairs, n_pairs) - 1u; // the cluster's last pair
+                // lanes past the cluster's end repeat its last pair: the same hits once more, which the atomic minimum absorbs
+                const uint32_t j = min(first + chunk + my_pair, last);
+                pd = load_pair(tri2, j);
+                orig = reinterpret_cast<const uint2*>(tri_orig)[j];
+            };
+            while (todo) {
+                const uint32_t c = (uint32_t)__ffsll((long long)todo) - 1u;
+                todo &= todo - 1;
+                PairData pd;
+                uint2 orig;
+                fetch(c, 0, pd, orig);
+                const uint32_t first_ref = __shfl(cincl - mine_cnt - before_round, (int)c);
+                const uint32_t n_c = __shfl(mine_cnt, (int)c);
+                if (cl_stat && lane == 0) atomicAdd(&cl_stat[(size_t)(first_cluster + c) * kCountStride], n_c); // statistics
+                for (uint32_t chunk = 0;;) {
+                    for (uint32_t k0 = 0; k0 < n_c; k0 += 8) {
+                        const uint32_t k = k0 + my_ray;
+                        const uint32_t e = refs[first_ref + min(k, n_c - 1u)];
+                        const float4 o4 = rays[2 * e], d4 = rays[2 * e + 1];
+                        pair_hits(pd, k < n_c, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, d4.w, [&](int h, float num, float den) {
+                            flush_hit(pend, best); // (rare: an earlier hit of this lane is still pending)
+                            pend.num = num; pend.den = den; pend.entry = e;
+                            pend.orig = h ? orig.y : orig.x;
+                        });
                     }
-                __syncthreads();
-
-                // ---- scan: (cluster, 64 references) units
-                const bool mine_in = lane >= c_lo && lane < c_hi;
-                const uint32_t my_units = mine_in ? (mine_cnt + 63u) / 64u : 0u;
-                const uint32_t uincl = scan16(my_units, lane);
-                const uint32_t n_units = __shfl(uincl, 15);
-                for (;;) {
-                    uint32_t unit = 0;
-                    if (lane == 0) unit = atomicAdd(&next_unit, 1u);
-                    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-                    if (unit >= n_units) break;
-                    // the cluster that holds this unit: the last one with units whose first unit is <= unit
-                    const unsigned long long cand = __ballot(lane < kFusedGroup && my_units > 0 && uincl - my_units <= unit);
-                    const uint32_t c = 63u - (uint32_t)__clzll((long long)cand);
-                    const uint32_t first_ref = __shfl(cincl - mine_cnt - before_round, (int)c) + (unit - __shfl(uincl - my_units, (int)c)) * 64u;
-                    const uint32_t n_c = __shfl(mine_cnt, (int)c);
-                    const uint32_t n_u = min(64u, n_c - (unit - __shfl(uincl - my_units, (int)c)) * 64u);
-                    if (cl_stat && lane == 0) atomicAdd(&cl_stat[(size_t)(first_cluster + c) * kCountStride], n_u); // statistics
-                    const uint32_t first = (first_cluster + c) * cluster_pairs;
-                    const uint32_t last = min(first + cluster_pairs, n_pairs) - 1u; // the cluster's last pair
-                    for (uint32_t chunk = first;; ) {
-                        // lanes past the cluster's end repeat its last pair: the same hits once more, which the atomic minimum absorbs
-                        const uint32_t j = min(chunk + my_pair, last);
-                        PairData pd;
-                        uint2 orig;
-                        if constexpr (kTriLds) {
-                            const f2* __restrict__ t = reinterpret_cast<const f2*>(tri_s) + 12 * (j - group_first_pair);
-#pragma unroll
-                            for (int k = 0; k < 12; k++) pd.v[k] = t[k];
-                            orig = make_uint2(orig_s[2 * (j - group_first_pair)], orig_s[2 * (j - group_first_pair) + 1]);
-                        } else {
-                            pd = load_pair(tri2, j);
-                            orig = reinterpret_cast<const uint2*>(tri_orig)[j];
-                        }
-                        for (uint32_t k0 = 0; k0 < n_u; k0 += 8) {
-                            const uint32_t k = k0 + my_ray;
-                            const uint32_t e = refs_s[first_ref + min(k, n_u - 1u)];
-                            const float4 o4 = ray_s[2 * e], d4 = ray_s[2 * e + 1];
-                            pair_hits(pd, k < n_u, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, d4.w, [&](int h, float num, float den) {
-                                flush_hit(pend, hit); // (rare: an earlier hit of this lane is still pending)
-                                pend.num = num; pend.den = den; pend.slot = __float_as_uint(o4.w);
-                                pend.orig = h ? orig.y : orig.x;
-                            });
-                        }
-                        chunk += 8; // clusters of more than eight pairs: the next eight
-                        if (chunk > last) break;
-                    }
+                    chunk += 8; // clusters of more than eight pairs: the next eight
+                    if (chunk >= cluster_pairs || (first_cluster + c) * cluster_pairs + chunk >= n_pairs) break;
+                    fetch(c, chunk, pd, orig);
                 }
-                __syncthreads();
-                c_lo = c_hi;
             }
-            flush_hit(pend, hit);
+            c_lo = c_hi;
+            if (c_lo < boxes) wave_sync(); // the references of this round have been read: the pool is free for the next
         }
+        flush_hit(pend, best);
+        wave_sync();
+        // ---- the rays that were hit, to their slots
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const uint32_t e = i * 64 + lane;
+            const unsigned long long key = best[e];
+            if (key != kNoHit) atomicMin(&hit[__float_as_uint(rays[2 * e].w)], key);
+        }
+        wave_sync(); // the rays of this run have been read: the next run may overwrite them
     }
 }
 

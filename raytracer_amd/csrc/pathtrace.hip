@@ -204,14 +204,12 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     if (queue_entries > 0xffffffffu) { rt_set_error("batch too large for the ray queue"); return RT_ERR_INVALID; }
     // cluster lists: one tile of rays at a time if the whole queue would not fit the budget
     const size_t nc = d.n_clusters, ng = d.n_groups;
-    // k_group_clusters keeps the per-cluster lists in LDS and reads the groups' rays from bit maps: no lists at all
-    const size_t lists_nc = d.fused_groups ? 0 : nc, lists_ng = d.fused_groups ? 0 : ng;
-    const size_t bits_stride = d.fused_groups ? queue_entries / 64 : 0; // (shard_capacity is a multiple of 64)
+    const size_t lists_nc = d.fused_groups ? 0 : nc; // k_group_clusters keeps the per-cluster lists in LDS
     size_t list_capacity = 0, tiles = 1;
-    if (nc > 1 && !d.fused_groups) {
+    if (nc > 1) {
         // a tile is a range of 256-ray blocks; every shard may end in a partial block
         const size_t max_blocks = ((shard_capacity + kBlock - 1) / kBlock) * kShards;
-        list_capacity = list_budget / (4 * (lists_nc + lists_ng)) / kBlock * kBlock;
+        list_capacity = list_budget / (4 * (lists_nc + ng)) / kBlock * kBlock;
         if (list_capacity > max_blocks * kBlock) list_capacity = max_blocks * kBlock;
         if (list_capacity < kBlock) list_capacity = kBlock;
         tiles = (max_blocks + list_capacity / kBlock - 1) / (list_capacity / kBlock);
@@ -219,7 +217,6 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     const size_t slots_cl = (size_t)n_counters * tiles;
     const size_t q_words = (size_t)n_counters * kShards * kCountStride;
     const size_t cl_words = slots_cl * nc * kCountStride, grp_words = slots_cl * ng * kCountStride;
-    const size_t piece_words = d.fused_groups ? (size_t)n_counters * kCountStride : 0;
     const size_t live_capacity = ((n_waves + kShards - 1) / kShards) * 64; // a wavefront keeps at most its 64 paths
     const size_t live_total = kShards * live_capacity; // >= n_paths: buffer 0 also holds the camera rays at the paths' own indices
     if (2 * live_total + (size_t)n_paths * nl > 0xffffffffu) { rt_set_error("batch too large for 32-bit hit slots"); return RT_ERR_INVALID; }
@@ -234,22 +231,19 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     w.hit = c.take<unsigned long long>(2 * live_total + (size_t)n_paths * nl);
     w.q_o = c.take<float4>(2 * queue_entries);
     w.q_d = w.q_o + 1;
-    w.q_count = c.take<uint32_t>(2 * q_words + cl_words + grp_words + piece_words); // one block: cleared with one fill
+    w.q_count = c.take<uint32_t>(2 * q_words + cl_words + grp_words); // one block: cleared with one fill
     w.live_count = w.q_count + q_words;
     w.cl_count = w.live_count + q_words;
     w.grp_count = w.cl_count + cl_words;
-    w.piece_count = w.grp_count + grp_words;
     w.live = c.take<uint32_t>(2 * kShards * live_capacity);
     w.cast_count = c.take<uint32_t>((size_t)n_counters * kCastShards * kCountStride);
     w.cl_list = c.take<uint32_t>(lists_nc * list_capacity);
-    w.grp_list = c.take<uint32_t>(lists_ng * list_capacity);
-    w.grp_bits = c.take<unsigned long long>(ng * bits_stride);
-    w.bits_stride = (uint32_t)bits_stride;
+    w.grp_list = c.take<uint32_t>(ng * list_capacity);
     w.live_total = (uint32_t)live_total;
     w.live_capacity = (uint32_t)live_capacity;
     w.shard_capacity = (uint32_t)shard_capacity;
     w.list_capacity = (uint32_t)list_capacity;
-    ws->counter_words = 2 * q_words + cl_words + grp_words + piece_words;
+    ws->counter_words = 2 * q_words + cl_words + grp_words;
     ws->tiles = (uint32_t)tiles;
     ws->paths = n_paths;
     ws->n_counters = n_counters;
@@ -326,37 +320,7 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
     int rc;
     const f2* tri2 = reinterpret_cast<const f2*>(s->d.tri_pair);
     const uint32_t* q_count = w.q_count + (size_t)counter * kShards * kCountStride;
-    if (cull && s->d.fused_groups) {
-        // groups of at most 16 clusters: the rays are marked per group (one bit per queue position), then a
-        // workgroup expands a piece of one group's marks, bins it into the group's clusters and scans them
-        const uint32_t nc = s->d.n_clusters, ng = s->d.n_groups;
-        uint32_t* cl_count = w.cl_count + (size_t)counter * nc * kCountStride;
-        uint32_t* grp_count = w.grp_count + (size_t)counter * ng * kCountStride;
-        if ((rc = mark('B')) != RT_OK) return rc;
-        // rays per lane and the number of persistent workgroups follow the batch: few workgroups mean few
-        // additions to the groups' counters (one per group and workgroup), many keep a short queue's latency low
-        static const int forced_rays = [] { const char* e = std::getenv("RT_AMD_MARK_RAYS"); return e ? std::atoi(e) : 0; }(); // tuning knob
-        static const int forced_mark_grid = [] { const char* e = std::getenv("RT_AMD_MARK_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
-        const int rays = forced_rays > 0 ? forced_rays : batch_paths >= 1536u * 1024u ? 2 : 1;
-        const uint32_t mark_grid = forced_mark_grid > 0 ? (uint32_t)forced_mark_grid : batch_paths >= 6u * 1024u * 1024u ? 2048u : 1024u;
-        auto mark_groups = rays >= 4 ? k_mark_groups<4> : rays == 2 ? k_mark_groups<2> : k_mark_groups<1>;
-        hipLaunchKernelGGL(mark_groups, dim3(mark_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
-                           (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity, w.grp_bits, w.bits_stride, grp_count);
-        if ((rc = mark('M')) != RT_OK) return rc;
-        // pieces of about two passes (2 x 1 024 marked rays); three workgroups of 512 threads fit a CU
-        static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
-        static const int forced_piece = [] { const char* e = std::getenv("RT_AMD_PIECE"); return e ? std::atoi(e) : 0; }(); // tuning knob
-        const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : 768u;
-        const uint32_t piece_entries = forced_piece > 0 ? (uint32_t)forced_piece : 2048u;
-        auto group_clusters = s->d.cluster_pairs <= kClusterPairs ? k_group_clusters<512, true> : k_group_clusters<512, false>;
-        hipLaunchKernelGGL(group_clusters, dim3(grid), dim3(512), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
-                           s->d.cluster_pairs, ng, s->d.group_clusters, reinterpret_cast<const f2*>(s->d.cl_pair),
-                           (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
-                           (const unsigned long long*)w.grp_bits, w.bits_stride, (const uint32_t*)grp_count, piece_entries,
-                           w.piece_count + (size_t)counter * kCountStride, w.hit, count_tests ? cl_count : (uint32_t*)nullptr);
-        if ((rc = mark('E')) != RT_OK) return rc;
-    } else if (cull && s->d.n_clusters > 1) {
-        // larger meshes: per-group and per-cluster lists of queue positions in global memory
+    if (cull && s->d.n_clusters > 1) {
         const uint32_t nc = s->d.n_clusters;
         const uint32_t blocks_per_tile = w.list_capacity / kBlock;
         for (uint32_t tile = 0; tile < ws.tiles; tile++) {
@@ -369,7 +333,9 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
             bool wider = batch_paths >= 6u * 1024u * 1024u;
             // Half the resident workgroups for batches below 6 M paths: every workgroup of these grids pays a
             // set-up (shard map, job table) whether it finds work or not, and with several frames in flight
-            // the short stages of small batches are mostly set-up.
+            // the short stages of small batches are mostly set-up.  (Measured with three frames in flight:
+            // 2 048 workgroups are best at 8.4 M paths, 1 024 at 4.2 M and below -- 9 % at 1 M; a frame
+            // rendered alone loses 2 % against 4 096.)
             static const int forced_grid = [] { const char* e = std::getenv("RT_AMD_BIN_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
             const uint32_t bin_grid = forced_grid > 0 ? (uint32_t)forced_grid : batch_paths >= 6u * 1024u * 1024u ? kMeshGrid : kMeshGrid / 2, cl_grid = bin_grid;
             static const int forced = [] { const char* e = std::getenv("RT_AMD_BIN_RAYS"); return e ? std::atoi(e) : 0; }(); // tuning knob
@@ -382,14 +348,33 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
             hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
                                (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
                                tile * blocks_per_tile, blocks_per_tile, grp_count, w.grp_list, w.list_capacity);
-            auto bin_groups = wider ? k_bin_groups<4> : wide ? k_bin_groups<2> : k_bin_groups<1>;
-            hipLaunchKernelGGL(bin_groups, dim3(bin_grid), dim3(kBlock), 0, stream, cl_pair, nc, ng, s->d.group_clusters,
-                               (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)grp_count,
-                               (const uint32_t*)w.grp_list, cl_count, w.cl_list, w.list_capacity);
-            if ((rc = mark('M')) != RT_OK) return rc;
-            hipLaunchKernelGGL(k_mesh_clusters, dim3(cl_grid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
-                               s->d.cluster_pairs, (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)cl_count,
-                               (const uint32_t*)w.cl_list, w.list_capacity, w.hit);
+            if (s->d.fused_groups) {
+                // second level and triangle scan in one kernel: the per-cluster lists live in LDS
+                if ((rc = mark('M')) != RT_OK) return rc;
+                // 512 threads bin 1 024 list entries per pass (measured on the cat frame, 256 / 512 / 1 024 threads:
+                // 1.03 / 0.91 / 1.13 ms per frame).  Many more workgroups than fit the chip: a run is then one or
+                // two passes and the runs even out (768 / 3 072 / 6 144 workgroups: 1.20 / 0.90 / 0.87 ms).
+                // a wavefront per run of 256 list entries, no workgroup barriers: the grid is what fits the chip
+                // (LDS: four workgroups of four wavefronts per CU), the runs are dealt to its wavefronts in turn
+                static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
+                static const int fused_entries = [] { const char* e = std::getenv("RT_AMD_FUSED_ENTRIES"); return e ? std::atoi(e) : 0; }(); // tuning knob
+                const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : 1024u;
+                auto group_clusters = fused_entries == 2 ? k_group_clusters<2> : fused_entries == 3 ? k_group_clusters<3> : k_group_clusters<4>;
+                hipLaunchKernelGGL(group_clusters, dim3(grid), dim3(kBlock), 0, stream,
+                                   tri2, s->d.tri_orig, s->d.n_triangles, nc,
+                                   s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
+                                   (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,
+                                   count_tests ? cl_count : (uint32_t*)nullptr);
+            } else {
+                auto bin_groups = wider ? k_bin_groups<4> : wide ? k_bin_groups<2> : k_bin_groups<1>;
+                hipLaunchKernelGGL(bin_groups, dim3(bin_grid), dim3(kBlock), 0, stream, cl_pair, nc, ng, s->d.group_clusters,
+                                   (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)grp_count,
+                                   (const uint32_t*)w.grp_list, cl_count, w.cl_list, w.list_capacity);
+                if ((rc = mark('M')) != RT_OK) return rc;
+                hipLaunchKernelGGL(k_mesh_clusters, dim3(cl_grid), dim3(kBlock), 0, stream, tri2, s->d.tri_orig, s->d.n_triangles, nc,
+                                   s->d.cluster_pairs, (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)cl_count,
+                                   (const uint32_t*)w.cl_list, w.list_capacity, w.hit);
+            }
             if ((rc = mark('E')) != RT_OK) return rc;
         }
     } else {
@@ -832,7 +817,6 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
                 const size_t slots = (size_t)n_counters * ws.tiles * kCountStride * sizeof(uint32_t);
                 HIP_TRY(hipMemsetAsync(w.cl_count, 0, slots * s->d.n_clusters, stream));
                 if (s->d.n_groups) HIP_TRY(hipMemsetAsync(w.grp_count, 0, slots * s->d.n_groups, stream));
-                if (s->d.fused_groups) HIP_TRY(hipMemsetAsync(w.piece_count, 0, (size_t)n_counters * kCountStride * sizeof(uint32_t), stream));
             }
         }
         if (stats) HIP_TRY(hipMemsetAsync(w.cast_count, 0, cast_counts.size() * sizeof(uint32_t), stream));
@@ -1168,9 +1152,11 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
     rc = RT_OK;
     do {
         if (hipMemcpy(d_a, a, 3 * (size_t)n * 4, hipMemcpyHostToDevice) || hipMemcpy(d_b, b, 3 * (size_t)n * 4, hipMemcpyHostToDevice) ||
-            hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(w.q_count, 0, s->ws.counter_words * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; } // (every counter of the work set)
+            hipMemset(d_abg, 0, 3 * (size_t)n * 4) || hipMemset(w.q_count, 0, 2 * kShards * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, w, f, (const float*)d_a, (const float*)d_b, as_segments);
         const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
+        if (cull && hipMemset(w.cl_count, 0, (size_t)2 * s->ws.tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        if (cull && s->d.n_groups && hipMemset(w.grp_count, 0, (size_t)2 * s->ws.tiles * s->d.n_groups * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         if (launch_mesh(s, s->ws, 0, nullptr, false, cull, n, false) != RT_OK) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }
