@@ -874,6 +874,149 @@ __global__ __launch_bounds__(kBlock) void k_group_clusters(const f2* __restrict_
     }
 }
 
+// The workgroup version (kept for comparison while the wavefront version is tuned).
+template <int R, int T, int U>
+__global__ __launch_bounds__(T) void k_group_clusters_wg(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
+                                                      uint32_t n_clusters, uint32_t cluster_pairs, uint32_t n_groups,
+                                                      uint32_t group_clusters, const f2* __restrict__ cl_pair,
+                                                      const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                      const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_list,
+                                                      uint32_t list_capacity, unsigned long long* __restrict__ hit,
+                                                      uint32_t* __restrict__ cl_stat) {
+    constexpr uint32_t kPass = R * T;                    // list entries per pass
+    constexpr uint32_t kWaves = T / 64;
+    constexpr uint32_t kUnit = kPass / U;                // entries a scan unit looks at
+    static_assert(kUnit % 64 == 0 && kPass <= 65536, "units are whole 64-entry blocks; entry numbers are 16 bits wide");
+    __shared__ float4 ray_s[2 * kPass];                  // this pass's rays: origin + hit slot, direction + cut-off
+    __shared__ uint16_t mask_s[kPass];                   // the clusters of the group each entry's ray touches
+    __shared__ uint16_t refs_s[kWaves][kUnit];           // per wavefront: the entries of the unit it scans
+    __shared__ uint32_t first_run[kFusedMaxGroups + 1];  // runs of the groups before each group
+    __shared__ uint32_t run_entries_s, next_unit;
+    __shared__ unsigned long long best_s[kPass];         // nearest hit of each of the pass's rays so far
+
+    // ---- plan: the groups' lists are cut into runs of `run_entries` entries (a multiple of kPass),
+    // sized so that every workgroup of the grid gets about one run; every workgroup computes the same plan
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        const uint32_t mine = lane < n_groups ? grp_count[lane * kCountStride] : 0;
+        uint32_t total = mine;
+#pragma unroll
+        for (int step = 1; step < 64; step <<= 1) total += __shfl_xor(total, step);
+        uint32_t passes = (total + gridDim.x * kPass - 1) / (gridDim.x * kPass);
+        passes = min(max(passes, 1u), 16u);
+        const uint32_t run_entries = passes * kPass;
+        const uint32_t runs = (mine + run_entries - 1) / run_entries;
+        uint32_t incl = runs;
+#pragma unroll
+        for (int step = 1; step < 64; step <<= 1) {
+            const uint32_t up = __shfl_up(incl, step);
+            if ((int)lane >= step) incl += up;
+        }
+        if (lane < n_groups) first_run[lane] = incl - runs;
+        if (lane == 63) first_run[n_groups] = incl; // lanes past n_groups add nothing: the total
+        if (lane == 0) run_entries_s = run_entries;
+    }
+    __syncthreads();
+    const uint32_t n_runs = first_run[n_groups], run_entries = run_entries_s;
+    const uint32_t n_pairs = (n_tri + 1) / 2;
+    const uint32_t my_pair = lane & 7u, my_ray = lane >> 3;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+
+    for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
+        // the group this run belongs to (first_run is non-decreasing; n_groups <= 64: one ballot)
+        const uint32_t fr = lane < n_groups ? first_run[lane] : 0xffffffffu;
+        const uint32_t g = (uint32_t)__popcll(__ballot(fr <= run)) - 1u;
+        const uint32_t count = grp_count[g * kCountStride];
+        const uint32_t run_begin = (run - first_run[g]) * run_entries;
+        const uint32_t run_end = min(run_begin + run_entries, count);
+        const uint32_t first_cluster = g * group_clusters; // even: a group starts a box pair
+        const uint32_t boxes = min(group_clusters, n_clusters - first_cluster);
+        const uint32_t real = (1u << boxes) - 1u;          // an odd count leaves half a box pair without a box
+        const uint32_t* __restrict__ my_list = grp_list + (size_t)g * list_capacity;
+
+        for (uint32_t pass = run_begin; pass < run_end; pass += kPass) {
+            // ---- bin: this pass's rays into LDS, their cluster masks beside them
+            SlabRay ray[R];
+            bool active[R];
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                const uint32_t e = pass + i * T + threadIdx.x;
+                active[i] = e < run_end;
+                const uint32_t pos = my_list[active[i] ? e : run_end - 1];
+                const float4 o4 = q_o[2 * (size_t)pos], d4 = q_d[2 * (size_t)pos];
+                ray_s[2 * (i * T + threadIdx.x)] = o4;
+                ray_s[2 * (i * T + threadIdx.x) + 1] = d4;
+                best_s[i * T + threadIdx.x] = kNoHit;
+                ray[i] = slab_ray(o4, d4);
+            }
+            uint32_t bits[R];
+            slab_bits<R>(cl_pair + 6 * (size_t)(first_cluster / 2), 0, (boxes + 1) / 2, ray, bits);
+#pragma unroll
+            for (int i = 0; i < R; i++) mask_s[i * T + threadIdx.x] = (uint16_t)(active[i] ? (bits[i] & real) : 0u);
+            if (threadIdx.x == 0) next_unit = 0;
+            __syncthreads();
+
+            // ---- scan: (cluster, part of the pass) units.  A wavefront works as 8 pairs x 8 rays.
+            const uint32_t n_units = U * boxes;
+            PendingHit pend;
+            pend.num = 0.f; pend.den = 1.f; pend.orig = 0xffffffffu; pend.entry = 0;
+            for (;;) {
+                uint32_t unit = 0;
+                if (lane == 0) unit = atomicAdd(&next_unit, 1u);
+                unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+                if (unit >= n_units) break;
+                const uint32_t c = unit / U, part = unit % U;
+                const uint32_t first = (first_cluster + c) * cluster_pairs;
+                const uint32_t last = min(first + cluster_pairs, n_pairs) - 1u; // the cluster's last pair
+                // this lane's pair of the cluster's first eight, requested before the work that hides its latency;
+                // lanes past the cluster's end repeat its last pair: the same hits once more, which the atomic minimum absorbs
+                uint32_t j = min(first + my_pair, last);
+                PairData pd = load_pair(tri2, j);
+                uint2 orig = reinterpret_cast<const uint2*>(tri_orig)[j];
+                // the unit's entries, in entry order, into this wavefront's list
+                uint32_t n = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < kUnit / 64; b++) {
+                    const uint32_t e = part * kUnit + b * 64 + lane;
+                    const bool touches = (mask_s[e] >> c) & 1u;
+                    const unsigned long long m = __ballot(touches);
+                    if (touches) refs_s[wave][n + (uint32_t)__popcll(m & below)] = (uint16_t)e;
+                    n += (uint32_t)__popcll(m);
+                }
+                if (n == 0) continue;
+                if (cl_stat && lane == 0) atomicAdd(&cl_stat[(size_t)(first_cluster + c) * kCountStride], n); // statistics
+                for (uint32_t chunk = first;;) {
+                    for (uint32_t k0 = 0; k0 < n; k0 += 8) {
+                        const uint32_t k = k0 + my_ray;
+                        const uint32_t e = refs_s[wave][min(k, n - 1u)];
+                        const float4 o4 = ray_s[2 * e], d4 = ray_s[2 * e + 1];
+                        pair_hits(pd, k < n, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, d4.w, [&](int h, float num, float den) {
+                            flush_hit(pend, best_s); // (rare: an earlier hit of this lane is still pending)
+                            pend.num = num; pend.den = den; pend.entry = e;
+                            pend.orig = h ? orig.y : orig.x;
+                        });
+                    }
+                    chunk += 8; // clusters of more than eight pairs: the next eight
+                    if (chunk > last) break;
+                    j = min(chunk + my_pair, last);
+                    pd = load_pair(tri2, j);
+                    orig = reinterpret_cast<const uint2*>(tri_orig)[j];
+                }
+            }
+            flush_hit(pend, best_s);
+            __syncthreads();
+            // the rays that were hit, to their slots
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                const uint32_t e = i * T + threadIdx.x;
+                const unsigned long long key = best_s[e];
+                if (key != kNoHit) atomicMin(&hit[__float_as_uint(ray_s[2 * e].w)], key);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
                                                           uint32_t n_clusters, uint32_t cluster_pairs,
                                                           const float4* __restrict__ q_o, const float4* __restrict__ q_d,
