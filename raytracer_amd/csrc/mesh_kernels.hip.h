@@ -395,29 +395,14 @@ __device__ __forceinline__ SlabRay slab_ray(float4 o4, float4 d4) {
 // of the test, or 0 * inf) are dropped by the minimum / maximum: that axis does
 // not constrain the ray, which errs towards "touches".  The box
 // data of an iteration (scalar loads) serves all R rays.
-// Bounds of a pair of boxes: lo.x lo.y lo.z hi.x hi.y hi.z, each as (box 2k, box 2k+1).
-struct BoxPair {
-    f2 v[6];
-};
-
-__device__ __forceinline__ BoxPair load_box_pair(const f2* __restrict__ box_pair, uint32_t k) {
-    BoxPair p;
-    const f2* __restrict__ g = box_pair + 6 * (size_t)k;
-#pragma unroll
-    for (int i = 0; i < 6; i++) p.v[i] = g[i];
-    return p;
-}
-
 template <int R>
 __device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint32_t first, uint32_t last, const SlabRay (&ray)[R],
                                           uint32_t (&bits)[R]) {
 #pragma unroll
     for (int i = 0; i < R; i++) bits[i] = 0;
-    if (first >= last) return;
-    // The box data arrives by scalar loads, whose only wait is "all of them": the next pair is requested right after
-    // that wait and before the current pair is tested, so that a load is in flight during every test (as in scan_pairs).
-    auto test = [&](const BoxPair& p) {
-        const f2 b0 = p.v[0], b1 = p.v[1], b2 = p.v[2], b3 = p.v[3], b4 = p.v[4], b5 = p.v[5];
+    for (uint32_t k = first; k < last; k++) {
+        const f2* __restrict__ b = box_pair + 6 * (size_t)k;
+        const f2 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const SlabRay& r = ray[i];
@@ -435,23 +420,11 @@ __device__ __forceinline__ void slab_bits(const f2* __restrict__ box_pair, uint3
                 "v_cmp_ge_f32 vcc, %3, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                 : "+v"(bits[i]) : "v"(out0), "v"(in0), "v"(out1), "v"(in1) : "vcc");
         }
-    };
-    // two pairs per trip, two register sets: each set is requested right after a wait and just before the OTHER set is tested
-    BoxPair cur = load_box_pair(box_pair, first);
-    for (uint32_t k = first; k < last; k += 2) {
-        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): `cur` has landed
-        const BoxPair nxt = load_box_pair(box_pair, min(k + 1, last - 1));
-        __builtin_amdgcn_sched_barrier(0); // keep the request ahead of the tests it overlaps
-        test(cur);
-        __builtin_amdgcn_s_waitcnt(0xC07F); // `nxt` has landed
-        cur = load_box_pair(box_pair, min(k + 2, last - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 1 < last) test(nxt);
     }
     // box 2 (k - first) + h to bit 2 (k - first) + h
     const uint32_t used = 2 * (last - first);
 #pragma unroll
-    for (int i = 0; i < R; i++) bits[i] = __brev(bits[i]) >> (32 - used);
+    for (int i = 0; i < R; i++) bits[i] = used ? __brev(bits[i]) >> (32 - used) : 0u;
 }
 
 // The boxes (up to 64, as a bit mask) that S rays per lane enter before their
@@ -584,299 +557,50 @@ __global__ __launch_bounds__(kBlock) void k_bin_groups(const f2* __restrict__ cl
     }
 }
 
-// ---- meshes of up to kFusedMaxGroups * kFusedGroup clusters: marks instead of lists -------------
+// ---- second level and triangle scan in one kernel ---------------------------
 //
-// For these meshes the groups hold at most kFusedGroup clusters each, and nothing but bits goes
-// through memory between the two levels:
+// For meshes of up to kFusedMaxGroups * kFusedGroup clusters the groups hold at most kFusedGroup
+// clusters each, and the rays on a group's list are binned into that group's clusters and scanned
+// against the clusters' triangles by the same workgroup, through LDS: no per-cluster lists in
+// global memory, no global reservations, no job table, one kernel less per triangle stage.
 //
-//   k_mark_groups      every queued ray against the group boxes.  The verdicts of the 64 rays of a
-//                      wavefront (64 consecutive queue positions) are one 64-bit word per group,
-//                      written to that group's bit map at word (queue position / 64): no lists,
-//                      no reservations, no barriers -- a streaming kernel.  The set bits are counted
-//                      per group on the way (one atomic per group and workgroup, at the end).
-//   k_group_clusters   a workgroup takes a PIECE: one group and a range of bit-map words sized from
-//                      the group's count so that it holds about two passes of rays.  It expands the
-//                      set bits into queue positions, bins those rays into the group's clusters and
-//                      scans the clusters' triangles, all through LDS.
+// A workgroup of T threads takes a contiguous run of one group's list (a few passes of R * T
+// entries).  A pass has two phases:
 //
-// (First version: per-group LISTS of queue positions, filled through one global reservation per
-// group and workgroup with three barriers per block of rays -- latency-bound at a third of the
-// chip's issue rate, and provisioned for the worst case: 1.1 GB per scene handle where the bit
-// maps take 34 MB.)
-
-// Shard and index within it of this lane's ray in ray block `ray_block` (kBlock rays, one per thread);
-// `count` is the shard's ray count (the ray exists when r < count).
-__device__ __forceinline__ void ray_in_shard(const ShardMap& m, uint32_t ray_block, uint32_t& shard, uint32_t& r, uint32_t& count) {
-    shard = (uint32_t)__popcll(__ballot(m.before <= ray_block)) - 1u; // `before` is non-decreasing
-    const uint32_t shard_first = __shfl(m.before, (int)shard);
-    count = __shfl(m.my_count, (int)shard);
-    r = (ray_block - shard_first) * kBlock + threadIdx.x;
-}
-
-template <int R>
-__global__ __launch_bounds__(kBlock) void k_mark_groups(const f2* __restrict__ grp_pair, uint32_t n_groups,
-                                                        const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                        const uint32_t* __restrict__ q_count, uint32_t shard_capacity,
-                                                        unsigned long long* __restrict__ grp_bits, uint32_t bits_stride,
-                                                        uint32_t* __restrict__ grp_count) {
-    __shared__ uint32_t total_s[kFusedMaxGroups];
-    const ShardMap map = load_shard_map(q_count);
-    const uint32_t lane = __lane_id();
-    if (threadIdx.x < kFusedMaxGroups) total_s[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t marked = 0; // lane g: rays this wavefront marked for group g
-    for (uint32_t ray_block = R * blockIdx.x; ray_block < map.n_ray_blocks; ray_block += R * gridDim.x) {
-        bool active[R];
-        uint32_t at[R], word[R];
-#pragma unroll
-        for (int i = 0; i < R; i++) {
-            active[i] = false;
-            at[i] = 0;
-            word[i] = 0;
-            if (ray_block + i < map.n_ray_blocks) {
-                uint32_t shard, r, count;
-                ray_in_shard(map, ray_block + i, shard, r, count);
-                active[i] = r < count;
-                // shard_capacity and kBlock are multiples of 64: the 64 rays of a wavefront share a word
-                word[i] = (shard * shard_capacity + r) >> 6;
-                at[i] = shard * shard_capacity + (active[i] ? r : count - 1);
-            }
-        }
-        unsigned long long mine[R];
-        if constexpr (R == 1) {
-            touched_boxes<1>(grp_pair, n_groups, active, at, q_o, q_d, mine);
-        } else {
-#pragma unroll
-            for (int i = 0; i < R; i += 2) touched_boxes<2>(grp_pair, n_groups, active + i, at + i, q_o, q_d, mine + i);
-        }
-#pragma unroll
-        for (int i = 0; i < R; i++) {
-            if (__ballot(active[i]) == 0) continue; // (the whole wavefront is past the shard's end: nobody reads that word)
-            const uint32_t lo = (uint32_t)mine[i], hi = (uint32_t)(mine[i] >> 32);
-            uint32_t w_lo = 0, w_hi = 0; // lane g collects group g's word
-            for (uint32_t g = 0; g < n_groups; g++) {
-                const unsigned long long b = __ballot(((g < 32 ? lo : hi) & (1u << (g & 31u))) != 0);
-                if (lane == g) { w_lo = (uint32_t)b; w_hi = (uint32_t)(b >> 32); }
-            }
-            if (lane < n_groups) {
-                grp_bits[(size_t)lane * bits_stride + word[i]] = ((unsigned long long)w_hi << 32) | w_lo;
-                marked += (uint32_t)__popc(w_lo) + (uint32_t)__popc(w_hi);
-            }
-        }
-    }
-    if (lane < n_groups && marked) atomicAdd(&total_s[lane], marked);
-    __syncthreads();
-    if (threadIdx.x < n_groups && total_s[threadIdx.x]) atomicAdd(&grp_count[threadIdx.x * kCountStride], total_s[threadIdx.x]);
-}
-
-// A lane's hit is final for that (ray, pair).  The hits of a run's rays are merged in LDS with the 64-bit minimum on
-// (t bits, caller's triangle index) -- the reference's "nearest, first triangle wins ties" whatever the order of
-// arrival -- and every ray that was hit goes to its slot in memory once, after the scan, with the atomic minimum that
-// merges runs, clusters and chunks anyway.  (No store or atomic to memory inside the scan: on this hardware loads and
-// stores complete out of order with respect to each other and share one counter, so a pending store turns every wait
-// for a load into a wait for everything, which would defeat the prefetch of the next cluster's triangles.)
-// The exact quotient of an accepted hit is deferred (`pend`): a lane flushes it when its next hit arrives or the run
-// ends, so the divisions of several trips' hits run together.
+//   bin    every lane fetches its entries' rays, keeps them in LDS (32 bytes each) and tests them
+//          against the group's cluster boxes: a 16-bit mask per entry, also in LDS;
+//   scan   the wavefronts draw (cluster, half of the pass) units from a counter.  A unit's entries
+//          are compacted into the wavefront's own list, and the wavefront then works as 8 triangle
+//          pairs x 8 rays: a lane keeps ONE pair of the cluster in registers for the whole unit
+//          (clusters of more than 8 pairs: one chunk of 8 after the other) and meets a new ray, read
+//          from LDS, every trip -- 128 ray-triangle tests per trip, the packed arithmetic of k_mesh.
+//
+// Compared with a lane per ray and a wave-uniform triangle (k_mesh, where thousands of rays share
+// one long triangle stream): no chain of dependent scalar loads per unit (a cluster is 8 steps
+// long, and the three workgroups of a CU walk different groups, which defeats the scalar cache),
+// rays come in eights instead of sixty-fours, so a unit of 37 rays wastes 3 slots instead of 27 and
+// nothing has to be carried from pass to pass, and the rays are read from memory once per pass.
+//
+// A lane's hit is final for that (ray, pair): it goes to the ray's slot with the 64-bit atomic
+// minimum on (t bits, caller's triangle index) that merges chunks and clusters anyway.  The exact
+// quotient of an accepted hit is deferred (`pend`): a lane flushes it when its next hit arrives
+// or the pass ends, so the division and the atomic run about once per pass, not once per trip.
 struct PendingHit {
     float num, den;
     uint32_t orig;   // caller's index of the triangle; 0xffffffff: none pending
-    uint32_t entry;  // the ray's entry number in the run
+    uint32_t slot;
 };
 
-__device__ __forceinline__ void flush_hit(PendingHit& pend, unsigned long long* best) {
+__device__ __forceinline__ void flush_hit(PendingHit& pend, unsigned long long* __restrict__ hit) {
     if (pend.orig != 0xffffffffu) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(pend.num / pend.den) << 32) | pend.orig;
-        atomicMin(&best[pend.entry], key);
+        atomicMin(&hit[pend.slot], key);
         pend.orig = 0xffffffffu;
     }
 }
 
-// Inclusive sum over the first 16 lanes' values (the other lanes' results are not used).
-__device__ __forceinline__ uint32_t scan16(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int step = 1; step < 16; step <<= 1) {
-        const uint32_t up = __shfl_up(v, step);
-        if ((int)lane >= step) v += up;
-    }
-    return v;
-}
-
-// Orders this wavefront's LDS traffic: what its lanes wrote before is visible to all of its lanes after.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Second level and triangle scan for meshes of up to kFusedMaxGroups * kFusedGroup clusters, one WAVEFRONT at a time:
-// a wavefront takes a run of 64 * E entries of one group's list and, on its own, without a workgroup barrier,
-//
-//   bins     every lane fetches E rays, keeps them in LDS (32 bytes each), tests them against the group's
-//            cluster boxes and counts per cluster (the 16-bit masks stay in registers);
-//   scatters the counts give every cluster a segment of a pool of references (2 * 64 * E entry numbers; if
-//            the run needs more, the clusters are taken in several rounds), and every lane drops its
-//            entries into the segments of the clusters they touch;
-//   scans    cluster after cluster as 8 triangle pairs x 8 rays: a lane keeps ONE pair of the cluster in
-//            registers (clusters of more than 8 pairs: one chunk of 8 after the other) and meets a new ray,
-//            read from LDS, every trip -- 128 ray-triangle tests per trip, the packed arithmetic of k_mesh.
-//            The first pairs of the next cluster are requested before the current one is scanned.
-//
-// (First version: a workgroup of 512 threads per 1 024 entries, phases separated by barriers: its wavefronts
-// spent a third of the time waiting for each other and for the phase's memory accesses, and every launch
-// took 25-45 us however short the lists.)
-template <int E>
-__global__ __launch_bounds__(kBlock) void k_group_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
-                                                           uint32_t n_clusters, uint32_t cluster_pairs, uint32_t n_groups,
-                                                           uint32_t group_clusters, const f2* __restrict__ cl_pair,
-                                                           const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                           const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_list,
-                                                           uint32_t list_capacity, unsigned long long* __restrict__ hit,
-                                                           uint32_t* __restrict__ cl_stat) {
-    constexpr uint32_t kRun = 64 * E;                    // entries per run
-    constexpr uint32_t kPool = 2 * kRun;                 // references per round
-    static_assert(kRun <= 256 && kFusedGroup == 16, "entry numbers are 8 bits wide; scan16 covers a group's clusters");
-    __shared__ float4 ray_s[kWavesPerBlock][2 * kRun];   // the run's rays: origin + hit slot, direction + cut-off
-    __shared__ uint8_t refs_s[kWavesPerBlock][kPool];    // entry numbers, one segment per cluster
-    __shared__ unsigned long long best_s[kWavesPerBlock][kRun]; // nearest hit of each of the run's rays so far
-    __shared__ uint32_t cnt_s[kWavesPerBlock][kFusedGroup], fill_s[kWavesPerBlock][kFusedGroup], base_s[kWavesPerBlock][kFusedGroup];
-    __shared__ uint32_t first_run[kFusedMaxGroups + 1];  // runs of the groups before each group
-
-    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    if (wave == 0) { // the plan, the same in every workgroup
-        const uint32_t mine = lane < n_groups ? grp_count[lane * kCountStride] : 0;
-        const uint32_t runs = (mine + kRun - 1) / kRun;
-        uint32_t incl = runs;
-#pragma unroll
-        for (int step = 1; step < 64; step <<= 1) {
-            const uint32_t up = __shfl_up(incl, step);
-            if ((int)lane >= step) incl += up;
-        }
-        if (lane < n_groups) first_run[lane] = incl - runs;
-        if (lane == 63) first_run[n_groups] = incl; // lanes past n_groups add nothing: the total
-    }
-    __syncthreads();
-    const uint32_t n_runs = first_run[n_groups];
-    const uint32_t n_pairs = (n_tri + 1) / 2;
-    const uint32_t my_pair = lane & 7u, my_ray = lane >> 3;
-    float4* __restrict__ rays = ray_s[wave];
-    uint8_t* __restrict__ refs = refs_s[wave];
-    uint32_t* __restrict__ cnt = cnt_s[wave];
-    uint32_t* __restrict__ fill = fill_s[wave];
-    uint32_t* __restrict__ base = base_s[wave];
-    unsigned long long* __restrict__ best = best_s[wave];
-
-    for (uint32_t run = blockIdx.x * kWavesPerBlock + wave; run < n_runs; run += gridDim.x * kWavesPerBlock) {
-        // the group this run belongs to (first_run is non-decreasing; groups without runs share their successor's value)
-        const uint32_t fr = lane < n_groups ? first_run[lane] : 0xffffffffu;
-        const uint32_t g = (uint32_t)__popcll(__ballot(fr <= run)) - 1u;
-        const uint32_t count = grp_count[g * kCountStride];
-        const uint32_t run_begin = (run - first_run[g]) * kRun;
-        const uint32_t n_e = min(kRun, count - run_begin);
-        const uint32_t first_cluster = g * group_clusters; // even: a group starts a box pair
-        const uint32_t boxes = min(group_clusters, n_clusters - first_cluster);
-        const uint32_t real = (1u << boxes) - 1u;          // an odd count leaves half a box pair without a box
-        const uint32_t* __restrict__ my_list = grp_list + (size_t)g * list_capacity + run_begin;
-
-        // ---- bin
-        if (lane < kFusedGroup) { cnt[lane] = 0; fill[lane] = 0; }
-        SlabRay ray[E];
-        bool active[E];
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            const uint32_t e = i * 64 + lane;
-            active[i] = e < n_e;
-            const uint32_t pos = my_list[active[i] ? e : n_e - 1];
-            const float4 o4 = q_o[2 * (size_t)pos], d4 = q_d[2 * (size_t)pos];
-            rays[2 * e] = o4;
-            rays[2 * e + 1] = d4;
-            best[e] = kNoHit;
-            ray[i] = slab_ray(o4, d4);
-        }
-        uint32_t cmask[E];
-        slab_bits<E>(cl_pair + 6 * (size_t)(first_cluster / 2), 0, (boxes + 1) / 2, ray, cmask);
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            cmask[i] = active[i] ? (cmask[i] & real) : 0u;
-            for (uint32_t m = cmask[i]; m; m &= m - 1) atomicAdd(&cnt[(uint32_t)__ffs((int)m) - 1u], 1u);
-        }
-        wave_sync();
-
-        // ---- the clusters in rounds of at most kPool references (one round, unless the rays touch many clusters each)
-        const uint32_t mine_cnt = lane < boxes ? cnt[lane] : 0u;
-        const uint32_t cincl = scan16(mine_cnt, lane);
-        PendingHit pend;
-        pend.num = 0.f; pend.den = 1.f; pend.orig = 0xffffffffu; pend.entry = 0;
-        for (uint32_t c_lo = 0; c_lo < boxes;) {
-            const uint32_t before_round = __shfl(cincl - mine_cnt, (int)c_lo);
-            // (a cluster holds at most kRun <= kPool references: every round takes at least one cluster)
-            const unsigned long long over = __ballot(lane > c_lo && lane < boxes && cincl - before_round > kPool);
-            const uint32_t c_hi = over ? (uint32_t)__ffsll((long long)over) - 1u : boxes;
-            // ---- scatter
-            if (lane < kFusedGroup) { base[lane] = cincl - mine_cnt - before_round; if (c_lo > 0) fill[lane] = 0; }
-            wave_sync();
-            const uint32_t in_round = ((1u << c_hi) - 1u) & ~((1u << c_lo) - 1u);
-#pragma unroll
-            for (int i = 0; i < E; i++)
-                for (uint32_t m = cmask[i] & in_round; m; m &= m - 1) {
-                    const uint32_t c = (uint32_t)__ffs((int)m) - 1u;
-                    refs[base[c] + atomicAdd(&fill[c], 1u)] = (uint8_t)(i * 64 + lane);
-                }
-            wave_sync();
-
-            // ---- scan: the clusters of this round that hold references, one after the other
-            unsigned long long todo = __ballot(lane >= c_lo && lane < c_hi && mine_cnt > 0);
-            auto fetch = [&](uint32_t c, uint32_t chunk, PairData& pd, uint2& orig) {
-                const uint32_t first = (first_cluster + c) * cluster_pairs;
-                const uint32_t last = min(first + cluster_pairs, n_pairs) - 1u; // the cluster's last pair
-                // lanes past the cluster's end repeat its last pair: the same hits once more, which the atomic minimum absorbs
-                const uint32_t j = min(first + chunk + my_pair, last);
-                pd = load_pair(tri2, j);
-                orig = reinterpret_cast<const uint2*>(tri_orig)[j];
-            };
-            while (todo) {
-                const uint32_t c = (uint32_t)__ffsll((long long)todo) - 1u;
-                todo &= todo - 1;
-                PairData pd;
-                uint2 orig;
-                fetch(c, 0, pd, orig);
-                const uint32_t first_ref = __shfl(cincl - mine_cnt - before_round, (int)c);
-                const uint32_t n_c = __shfl(mine_cnt, (int)c);
-                if (cl_stat && lane == 0) atomicAdd(&cl_stat[(size_t)(first_cluster + c) * kCountStride], n_c); // statistics
-                for (uint32_t chunk = 0;;) {
-                    for (uint32_t k0 = 0; k0 < n_c; k0 += 8) {
-                        const uint32_t k = k0 + my_ray;
-                        const uint32_t e = refs[first_ref + min(k, n_c - 1u)];
-                        const float4 o4 = rays[2 * e], d4 = rays[2 * e + 1];
-                        pair_hits(pd, k < n_c, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, d4.w, [&](int h, float num, float den) {
-                            flush_hit(pend, best); // (rare: an earlier hit of this lane is still pending)
-                            pend.num = num; pend.den = den; pend.entry = e;
-                            pend.orig = h ? orig.y : orig.x;
-                        });
-                    }
-                    chunk += 8; // clusters of more than eight pairs: the next eight
-                    if (chunk >= cluster_pairs || (first_cluster + c) * cluster_pairs + chunk >= n_pairs) break;
-                    fetch(c, chunk, pd, orig);
-                }
-            }
-            c_lo = c_hi;
-            if (c_lo < boxes) wave_sync(); // the references of this round have been read: the pool is free for the next
-        }
-        flush_hit(pend, best);
-        wave_sync();
-        // ---- the rays that were hit, to their slots
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            const uint32_t e = i * 64 + lane;
-            const unsigned long long key = best[e];
-            if (key != kNoHit) atomicMin(&hit[__float_as_uint(rays[2 * e].w)], key);
-        }
-        wave_sync(); // the rays of this run have been read: the next run may overwrite them
-    }
-}
-
-// The workgroup version (kept for comparison while the wavefront version is tuned).
 template <int R, int T, int U>
-__global__ __launch_bounds__(T) void k_group_clusters_wg(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
+__global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
                                                       uint32_t n_clusters, uint32_t cluster_pairs, uint32_t n_groups,
                                                       uint32_t group_clusters, const f2* __restrict__ cl_pair,
                                                       const float4* __restrict__ q_o, const float4* __restrict__ q_d,
@@ -892,7 +616,6 @@ __global__ __launch_bounds__(T) void k_group_clusters_wg(const f2* __restrict__ 
     __shared__ uint16_t refs_s[kWaves][kUnit];           // per wavefront: the entries of the unit it scans
     __shared__ uint32_t first_run[kFusedMaxGroups + 1];  // runs of the groups before each group
     __shared__ uint32_t run_entries_s, next_unit;
-    __shared__ unsigned long long best_s[kPass];         // nearest hit of each of the pass's rays so far
 
     // ---- plan: the groups' lists are cut into runs of `run_entries` entries (a multiple of kPass),
     // sized so that every workgroup of the grid gets about one run; every workgroup computes the same plan
@@ -946,7 +669,6 @@ __global__ __launch_bounds__(T) void k_group_clusters_wg(const f2* __restrict__ 
                 const float4 o4 = q_o[2 * (size_t)pos], d4 = q_d[2 * (size_t)pos];
                 ray_s[2 * (i * T + threadIdx.x)] = o4;
                 ray_s[2 * (i * T + threadIdx.x) + 1] = d4;
-                best_s[i * T + threadIdx.x] = kNoHit;
                 ray[i] = slab_ray(o4, d4);
             }
             uint32_t bits[R];
@@ -959,7 +681,7 @@ __global__ __launch_bounds__(T) void k_group_clusters_wg(const f2* __restrict__ 
             // ---- scan: (cluster, part of the pass) units.  A wavefront works as 8 pairs x 8 rays.
             const uint32_t n_units = U * boxes;
             PendingHit pend;
-            pend.num = 0.f; pend.den = 1.f; pend.orig = 0xffffffffu; pend.entry = 0;
+            pend.num = 0.f; pend.den = 1.f; pend.orig = 0xffffffffu; pend.slot = 0;
             for (;;) {
                 uint32_t unit = 0;
                 if (lane == 0) unit = atomicAdd(&next_unit, 1u);
@@ -991,8 +713,8 @@ __global__ __launch_bounds__(T) void k_group_clusters_wg(const f2* __restrict__ 
                         const uint32_t e = refs_s[wave][min(k, n - 1u)];
                         const float4 o4 = ray_s[2 * e], d4 = ray_s[2 * e + 1];
                         pair_hits(pd, k < n, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, d4.w, [&](int h, float num, float den) {
-                            flush_hit(pend, best_s); // (rare: an earlier hit of this lane is still pending)
-                            pend.num = num; pend.den = den; pend.entry = e;
+                            flush_hit(pend, hit); // (rare: an earlier hit of this lane is still pending)
+                            pend.num = num; pend.den = den; pend.slot = __float_as_uint(o4.w);
                             pend.orig = h ? orig.y : orig.x;
                         });
                     }
@@ -1003,15 +725,7 @@ __global__ __launch_bounds__(T) void k_group_clusters_wg(const f2* __restrict__ 
                     orig = reinterpret_cast<const uint2*>(tri_orig)[j];
                 }
             }
-            flush_hit(pend, best_s);
-            __syncthreads();
-            // the rays that were hit, to their slots
-#pragma unroll
-            for (int i = 0; i < R; i++) {
-                const uint32_t e = i * T + threadIdx.x;
-                const unsigned long long key = best_s[e];
-                if (key != kNoHit) atomicMin(&hit[__float_as_uint(ray_s[2 * e].w)], key);
-            }
+            flush_hit(pend, hit);
             __syncthreads();
         }
     }

@@ -354,21 +354,9 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
                 // 512 threads bin 1 024 list entries per pass (measured on the cat frame, 256 / 512 / 1 024 threads:
                 // 1.03 / 0.91 / 1.13 ms per frame).  Many more workgroups than fit the chip: a run is then one or
                 // two passes and the runs even out (768 / 3 072 / 6 144 workgroups: 1.20 / 0.90 / 0.87 ms).
-                // a wavefront per run of 256 list entries, no workgroup barriers: the grid is what fits the chip
-                // (LDS: four workgroups of four wavefronts per CU), the runs are dealt to its wavefronts in turn
                 static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
-                static const int fused_entries = [] { const char* e = std::getenv("RT_AMD_FUSED_ENTRIES"); return e ? std::atoi(e) : 0; }(); // tuning knob
-                const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : 1024u;
-                auto group_clusters = fused_entries == 2 ? k_group_clusters<2> : fused_entries == 3 ? k_group_clusters<3> : k_group_clusters<4>;
-                static const bool wg_version = [] { const char* e = std::getenv("RT_AMD_KGC"); return e && e[0] == 'w' && e[1] == 'g'; }();
-                if (wg_version)
-                hipLaunchKernelGGL((k_group_clusters_wg<2, 512, 2>), dim3(batch_paths >= 6u * 1024u * 1024u ? 6144u : batch_paths >= 2u * 1024u * 1024u ? 3072u : 1024u), dim3(512), 0, stream,
-                                   tri2, s->d.tri_orig, s->d.n_triangles, nc,
-                                   s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
-                                   (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,
-                                   count_tests ? cl_count : (uint32_t*)nullptr);
-                else
-                hipLaunchKernelGGL(group_clusters, dim3(grid), dim3(kBlock), 0, stream,
+                const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : batch_paths >= 6u * 1024u * 1024u ? 6144u : batch_paths >= 2u * 1024u * 1024u ? 3072u : 1024u;
+                hipLaunchKernelGGL((k_group_clusters<2, 512, 2>), dim3(grid), dim3(512), 0, stream,
                                    tri2, s->d.tri_orig, s->d.n_triangles, nc,
                                    s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
                                    (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,
