@@ -32,10 +32,13 @@ class OrcCounters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
-def _load():
-    if not os.path.exists(ORACLE_LIB):
-        raise ImportError(f"{ORACLE_LIB} missing: run `make -C oracle`")
-    lib = C.CDLL(ORACLE_LIB)
+ORACLE_FMA_LIB = os.path.join(ORACLE_DIR, "libpathtrace_oracle_fma.so")  # built with contraction (see oracle/Makefile)
+
+
+def _load(path=ORACLE_LIB):
+    if not os.path.exists(path):
+        raise ImportError(f"{path} missing: run `make -C oracle`")
+    lib = C.CDLL(path)
     lib.orc_render_pixels.argtypes = [C.POINTER(rt.SceneDesc), C.POINTER(rt.Camera), C.POINTER(OrcOptions), _u32p,
                                       C.c_uint32, C.c_uint32, C.c_uint32, _f32p, _f32p, _u32p,
                                       C.POINTER(OrcCounters), C.c_int32]
@@ -64,8 +67,23 @@ def from_rt_options(o: rt.Options, use_libm=False):
     return OrcOptions(o.indirect, o.antialiasing, o.bounding_box, o.max_depth, o.seed, int(use_libm))
 
 
-def render_pixels(desc, cam, opt, pixels, sample_begin=0, sample_end=None, threads=0):
-    """Returns (rgb[n,3], sum[n,3], count[n], counters dict)."""
+def cpu_has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
+def load_fma_build():
+    """The oracle built with fused multiply-adds, or None where it was not built or the CPU cannot run it."""
+    if not (cpu_has_fma() and os.path.exists(ORACLE_FMA_LIB)):
+        return None
+    return _load(ORACLE_FMA_LIB)
+
+
+def render_pixels(desc, cam, opt, pixels, sample_begin=0, sample_end=None, threads=0, lib=None):
+    """Returns (rgb[n,3], sum[n,3], count[n], counters dict).  `lib`: another build of the oracle (load_fma_build)."""
+    lib = lib or globals()["lib"]
     px = np.ascontiguousarray(pixels, dtype=np.uint32)
     n = len(px)
     if sample_end is None:
@@ -81,9 +99,9 @@ def render_pixels(desc, cam, opt, pixels, sample_begin=0, sample_end=None, threa
     return rgb, ssum, cnt, counters.as_dict()
 
 
-def render_image(desc, cam, opt, threads=0):
+def render_image(desc, cam, opt, threads=0, lib=None):
     n = cam.width * cam.height
-    rgb, _, _, counters = render_pixels(desc, cam, opt, np.arange(n, dtype=np.uint32), threads=threads)
+    rgb, _, _, counters = render_pixels(desc, cam, opt, np.arange(n, dtype=np.uint32), threads=threads, lib=lib)
     return rgb.reshape(cam.height, cam.width, 3), counters
 
 
