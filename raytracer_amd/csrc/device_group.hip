@@ -288,6 +288,8 @@ extern "C" int rt_device_group_render(rt_device_group* g, const rt_camera* cam, 
         const ncclResult_t end = r.GroupEnd();
         if (res == ncclSuccess) res = end;
         if (res != ncclSuccess) {
+            // nothing of this frame may still run on a member's stream when the caller reuses or frees the buffers
+            for (Member& m : g->members) { (void)hipSetDevice(m.device); (void)hipStreamSynchronize(m.stream); }
             (void)hipSetDevice(previous);
             rt_set_error("rt_device_group_render: RCCL reduce: %s", r.GetErrorString(res));
             return RT_ERR_DEVICE;

@@ -70,6 +70,11 @@ class FrameRenderer:
     colour sums and sample counts of the sample range, for the image rows
     rows = (begin, end), into sum_tensor (4 floats per pixel of the whole
     image); resolve(sum_tensor, out_tensor) must write gamma(mean).  The
+    fourth float of a pixel is its sample count, and its SIGN carries meaning in
+    sums the HIP library wrote: a negative count marks a pixel whose sample loop
+    the reference ends after the first sample (direct light without
+    anti-aliasing, a diffuse first hit), so a resolve that divides must divide
+    by abs(count).  The
     defaults call the HIP library on the current CUDA stream; the CPU test
     suite injects host implementations to exercise the partition + reduction
     logic under the gloo backend.

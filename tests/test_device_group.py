@@ -86,6 +86,25 @@ def test_group_members_on_one_device_compose_the_frame(members, spp):
     np.testing.assert_allclose(img, single, rtol=4e-6, atol=1e-4)  # fp32 association across members
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("members", [2, 3])
+def test_pixels_that_end_after_one_sample_compose_across_members(members):
+    """Direct light without anti-aliasing: a diffuse first hit ends the pixel's sample loop after one sample
+    (reference src/raytrace.cu:340-346, 496-498), which the sums carry as a NEGATIVE sample count.  Each member ends
+    the loop on its own first sample, so such a pixel arrives as (members x L, -members): the same colour as the
+    single-device render's (L, -1), up to the rounding of (L + ... + L) / members."""
+    from helpers import load
+
+    s = load("mesh_scene", 96, 64, 6)
+    desc, cam = s.describe()
+    opt = rt.make_options(indirect=False, antialiasing=False, seed=7)
+    img, _ = rt.DeviceGroup(desc, [0] * members).render(cam, opt)
+    single, _ = s.upload().render(cam, opt)
+    assert np.all(img >= 0) and np.all(np.isfinite(img))  # (a resolve that divided by the signed count would negate colours)
+    np.testing.assert_allclose(img, single, rtol=4e-6, atol=1e-4)
+    assert (img == single).mean() > 0.9
+
+
 _RCCL_REHEARSAL = """
 import numpy as np
 import raytracer_amd as rt

@@ -67,7 +67,7 @@ def _host_callbacks(desc, n_pixels):
 
     def resolve(sum_tensor, out_tensor):
         buf = sum_tensor.view(n_pixels, 4).numpy()
-        mean = (np.float32(1) / buf[:, 3:4]) * buf[:, :3]
+        mean = (np.float32(1) / np.abs(buf[:, 3:4])) * buf[:, :3]  # (the HIP library's sums mark early-ended pixels by a negative count)
         out_tensor.view(n_pixels, 3).numpy()[:] = ob.math_probe("gamma", mean.ravel()).reshape(-1, 3)
 
     return accumulate, resolve
