@@ -7,7 +7,8 @@ collective's launch path and the stream overlap are exercised; the transfer
 itself is missing) and reports ms per frame.  ms(1) / ms(N) is an upper bound
 of the strong-scaling factor bench.py --gpus N can reach.
 
-    python tools/scaling_probe.py [N ...] [word ...]   # words select arrangements: serial, overlapped, two, three, four (also five, six, eight)
+    python tools/scaling_probe.py [N ...] [word ...]   # words select arrangements: serial, overlapped, two, three, four (also five, six, eight);
+                                                       # "fast": rt_options.arithmetic = 1
 """
 import gc
 import json
@@ -35,10 +36,10 @@ def main():
     scene.load_scene(os.path.join(rt.ASSETS, "scenes", "mesh_scene.json"))
     desc, cam = scene.describe()
     dev = scene.upload()
-    opt = rt.make_options(seed=1)
+    opt = rt.make_options(seed=1, arithmetic=1 if "fast" in sys.argv[1:] else 0)  # word "fast": rt_options.arithmetic = 1, as bench.py runs by default
     out = {}
     shares = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 4, 8]
-    only = [a for a in sys.argv[1:] if not a.isdigit()]  # e.g. "serial" or "three": arrangements whose label contains the word
+    only = [a for a in sys.argv[1:] if not a.isdigit() and a != "fast"]  # e.g. "serial" or "three": arrangements whose label contains the word
     words = {2: "two", 3: "three", 4: "four", 5: "five", 6: "six", 8: "eight"}
     arrangements = [f"{words[k]} handles" for k in (4, 3, 2)] + [True, False]
     arrangements = [f"{w} handles" for w in only if w in words.values() and f"{w} handles" not in arrangements] + arrangements
