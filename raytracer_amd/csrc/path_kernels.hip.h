@@ -19,6 +19,11 @@ struct Frame {
     uint32_t seed;
     int32_t indirect, antialiasing, bounding_box, max_depth;
     int32_t count_casts;    // count the rays tested against the spheres (statistics)
+    int32_t regenerate;     // k_generate leaves (accepted draw, walks the mesh) per path instead of the ray, and the first
+                            // bounce computes the camera ray again: 136 bytes of state per path that make no round trip
+                            // through memory, for some 150 instructions more in a kernel that is short of bandwidth,
+                            // not of issue slots (fast arithmetic only: there the two kernels compute the same bits
+                            // with a few dozen instructions; the exact arithmetic would pay a few hundred)
     int32_t prune_zero_terms; // work whose result can only add exact zeros is dropped: the mesh walk of a shadow
                               // ray with a zero contribution, the rest of a path whose weight is zero (not in
                               // the exhaustive mode, which keeps the reference's amount of work)
@@ -116,6 +121,52 @@ template <class M> __device__ __forceinline__ bool jitter_accepted(const rt_rng_
     return !(fabsf(dx) > 0.5f || fabsf(dy) > 0.5f);
 }
 
+// Every camera ray starts at the eye: the start-dependent half of the sphere test is the same for all paths
+// and is computed once per workgroup (same operations, same bits).  All threads must call it; the caller
+// synchronises the workgroup before eye_oc is read.
+template <class M>
+__device__ __forceinline__ void stage_eye(const DeviceScene& sc, const SceneCache& cache, const Frame& f, float4* eye_oc) {
+    if (threadIdx.x < min(sc.n_spheres, kSphereCache)) {
+        const V3 oc = mk(f.pos[0], f.pos[1], f.pos[2]) - xyz(cache.sphere[threadIdx.x]);
+        eye_oc[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, oc_norm2_m<M>(oc));
+    }
+}
+
+// The camera ray through pixel (ux, uy) (reference src/raytrace.cu:479-494); with anti-aliasing the pixel offset is
+// the draw at dimension `dim` of the path's stream, and `dim` moves past it.
+template <class M>
+__device__ __forceinline__ V3 camera_ray(const Frame& f, const rt_rng_key& key, uint32_t ux, uint32_t uy, uint32_t& dim) {
+    float dx = 0.f, dy = 0.f;
+    if (f.antialiasing) {
+        jitter_m<M>(key, dim, dx, dy);
+        dim += 2;
+    }
+    const float px = (float)ux + 0.5f + dx;
+    const float py = (float)uy + 0.5f + dy;
+    const V3 dir = normalize_m<M>(mk(div_m<M>(px - f.cx, f.fx), div_m<M>(py - f.cy, f.fy), 1.f));
+    return mk(dot_m<M>(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
+              dot_m<M>(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
+              dot_m<M>(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
+}
+
+// nearest_sphere for a ray that starts at the eye, with the halves stage_eye prepared
+template <class M>
+__device__ __forceinline__ float nearest_sphere_from_eye(const DeviceScene& sc, const SceneCache& cache, const float4* eye_oc, V3 start, V3 ray, int& sid) {
+    float ts = INFINITY;
+    sid = -1;
+    const uint32_t cached = min(sc.n_spheres, kSphereCache);
+    for (uint32_t i = 0; i < cached; i++) {
+        const float4 e = eye_oc[i];
+        sphere_step<M>(dot_m<M>(ray, xyz(e)), e.w, cache.sphere[i].w, i, ts, sid);
+    }
+    for (uint32_t i = cached; i < sc.n_spheres; i++) {
+        const float4 sph = sc.sphere[i];
+        const V3 oc = start - xyz(sph);
+        sphere_step<M>(dot_m<M>(ray, oc), oc_norm2_m<M>(oc), sph.w, i, ts, sid);
+    }
+    return ts;
+}
+
 template <uint32_t kPaths, class M>
 __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f) {
     __shared__ SceneCache cache;
@@ -123,12 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
     __shared__ uint32_t accepted[kPaths][kBlock]; // first dimension of the accepted draw
     __shared__ float4 eye_oc[kSphereCache];       // per cached sphere: OC = eye - centre, |OC| * |OC|
     stage_scene(sc, cache);
-    // every camera ray starts at the eye: the start-dependent half of the sphere test is the same
-    // for all paths and is computed once per workgroup (same operations, same bits)
-    if (threadIdx.x < min(sc.n_spheres, kSphereCache)) {
-        const V3 oc = mk(f.pos[0], f.pos[1], f.pos[2]) - xyz(cache.sphere[threadIdx.x]);
-        eye_oc[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, oc_norm2_m<M>(oc));
-    }
+    stage_eye<M>(sc, cache, f, eye_oc);
     __syncthreads();
     const uint32_t base = blockIdx.x * (kBlock * kPaths) + threadIdx.x;
     // only this lane reads what it writes to the three arrays: no barrier needed
@@ -169,46 +215,36 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
         const bool alive = p < f.n_paths;
         V3 start = mk(f.pos[0], f.pos[1], f.pos[2]);
         V3 ray = mk(0.f, 0.f, 1.f);
+        uint32_t first_dim = 0, dim = 0;
         if (alive) {
             const uint32_t pixel = path_pixel(f, p);
             const uint32_t ux = pixel % f.width, uy = pixel / f.width;
-            uint32_t dim = 0;
-            float dx = 0.f, dy = 0.f;
-            if (f.antialiasing) {
-                rt_rng_key key;
-                key.kp = key_kp[r][threadIdx.x];
-                key.ks = key_ks[r][threadIdx.x];
-                dim = accepted[r][threadIdx.x];
-                jitter_m<M>(key, dim, dx, dy);
-                dim += 2;
-            }
-            const float px = (float)ux + 0.5f + dx;
-            const float py = (float)uy + 0.5f + dy;
-            const V3 dir = normalize_m<M>(mk(div_m<M>(px - f.cx, f.fx), div_m<M>(py - f.cy, f.fy), 1.f));
-            ray = mk(dot_m<M>(mk(f.rot[0], f.rot[1], f.rot[2]), dir),
-                     dot_m<M>(mk(f.rot[3], f.rot[4], f.rot[5]), dir),
-                     dot_m<M>(mk(f.rot[6], f.rot[7], f.rot[8]), dir));
-            w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
-            w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
+            rt_rng_key key;
+            key.kp = key_kp[r][threadIdx.x];
+            key.ks = key_ks[r][threadIdx.x];
+            first_dim = dim = f.antialiasing ? accepted[r][threadIdx.x] : 0u;
+            ray = camera_ray<M>(f, key, ux, uy, dim);
         }
         int sid = -1;
         float ts = INFINITY;
         bool walk = false;
         if (alive) {
-            // nearest_sphere with the precomputed halves
-            const uint32_t cached = min(sc.n_spheres, kSphereCache);
-            for (uint32_t i = 0; i < cached; i++) {
-                const float4 e = eye_oc[i];
-                sphere_step<M>(dot_m<M>(ray, xyz(e)), e.w, cache.sphere[i].w, i, ts, sid);
-            }
-            for (uint32_t i = cached; i < sc.n_spheres; i++) {
-                const float4 sph = sc.sphere[i];
-                const V3 oc = start - xyz(sph);
-                sphere_step<M>(dot_m<M>(ray, oc), oc_norm2_m<M>(oc), sph.w, i, ts, sid);
-            }
+            ts = nearest_sphere_from_eye<M>(sc, cache, eye_oc, start, ray, sid);
             walk = needs_mesh<true, M>(sc, cache, f.bounding_box, ray, start);
         }
-        commit_ray(w, 0, alive, p, start, ray, ts, sid, walk);
+        if (f.regenerate) { // the first bounce computes the ray again: it needs the accepted draw and, if the ray walks the mesh, a hit slot
+            if (alive) {
+                w.gen[p] = first_dim | (walk ? kGenWalks : 0u);
+                if (walk) w.hit[p] = kNoHit;
+            }
+            enqueue(w, 0, alive && walk, start, ray, p, ts);
+        } else {
+            if (alive) {
+                w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
+                w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
+            }
+            commit_ray(w, 0, alive, p, start, ray, ts, sid, walk);
+        }
         n_casts += (uint32_t)__popcll(__ballot(alive));
     }
     if (f.count_casts) add_casts(w, 0, n_casts);
@@ -360,9 +396,12 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
 // the sphere scans and box tests of the shadow rays (diffuse hits) and of the
 // bounce ray.  The first light's shadow ray and the bounce ray of a diffuse
 // hit leave the same point, so their scans run as one (nearest_sphere_pair).
-template <class M>
+// kRegenerate (first bounce only, Frame::regenerate): the camera ray is computed again from what k_generate left in
+// Work::gen instead of being read back.
+template <class M, bool kRegenerate = false>
 __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& w, const Frame& f, int depth) {
     __shared__ SceneCache cache;
+    __shared__ float4 eye_oc[kRegenerate ? kSphereCache : 1];
     // The first bounce sees every path; later ones walk the list of paths the previous bounce
     // left alive, so that the lanes of a wavefront are all busy however many paths have ended.
     // A list entry is the path index, with kLivePending set when light terms of the previous
@@ -382,6 +421,10 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         pending = active && (entry & kLivePending) != 0;
     }
     stage_scene(sc, cache);
+    if constexpr (kRegenerate) {
+        stage_eye<M>(sc, cache, f, eye_oc);
+        __syncthreads();
+    }
     const uint32_t counter = (uint32_t)depth + 1u;
     bool alive = false; // the path continues with a bounce ray
     bool lit = false;   // diffuse hit: the lights are evaluated at `start`
@@ -393,15 +436,33 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
     uint32_t next_dim = 0;     // next random dimension of the path after this bounce
     bool tinted = false;       // the weight after this bounce is weight * colour (diffuse hit with indirect light)
     if (p < f.n_paths) {
-        // the whole state of the path in one round trip to memory
-        const float4 rad = w.rad[p];
-        const float4 ro4 = w.ray_o[index], rd4 = w.ray_d[index], th = w.thr[index];
-        const unsigned long long key = w.hit[index];
+        float4 rad, ro4, rd4, th;
+        unsigned long long key = kNoHit;
         float4 first_pend = make_float4(0.f, 0.f, 0.f, PEND_NONE);
         unsigned long long first_key = kNoHit;
-        if (pending) {
-            first_pend = w.pend[(size_t)p * sc.n_lights];
-            first_key = w.hit[shadow_base(w) + (size_t)p * sc.n_lights];
+        if constexpr (kRegenerate) {
+            const uint32_t g = w.gen[p];
+            if (g & kGenWalks) key = w.hit[p];
+            const uint32_t pixel = path_pixel(f, p);
+            const uint32_t ux = pixel % f.width, uy = pixel / f.width;
+            uint32_t dim = g & ~kGenWalks;
+            const V3 eye = mk(f.pos[0], f.pos[1], f.pos[2]);
+            const V3 cray = camera_ray<M>(f, rt_rng_make_key(f.seed, pixel, path_sample(f, p)), ux, uy, dim);
+            int csid;
+            const float cts = nearest_sphere_from_eye<M>(sc, cache, eye_oc, eye, cray, csid);
+            rad = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
+            th = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
+            ro4 = make_float4(eye.x, eye.y, eye.z, cts);
+            rd4 = make_float4(cray.x, cray.y, cray.z, __int_as_float(csid));
+        } else {
+            // the whole state of the path in one round trip to memory
+            rad = w.rad[p];
+            ro4 = w.ray_o[index], rd4 = w.ray_d[index], th = w.thr[index];
+            key = w.hit[index];
+            if (pending) {
+                first_pend = w.pend[(size_t)p * sc.n_lights];
+                first_key = w.hit[shadow_base(w) + (size_t)p * sc.n_lights];
+            }
         }
         flags = __float_as_uint(rad.w);
         if (flags & F_ALIVE) {
@@ -558,6 +619,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
 // rt_options.arithmetic = 1
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast(DeviceScene sc, Work w, Frame f, int depth) {
     shade_bounce<FastMath>(sc, w, f, depth);
+}
+
+// ... and its first bounce when the camera rays are regenerated (Frame::regenerate)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast_first(DeviceScene sc, Work w, Frame f) {
+    shade_bounce<FastMath, true>(sc, w, f, 0);
 }
 
 // ---- scenes without triangles: the whole sample loop in registers -------

@@ -227,6 +227,7 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     w.ray_d.base = rays + 1;
     w.thr = c.take<float4>(2 * live_total);
     w.rad = c.take<float4>(n_paths);
+    w.gen = c.take<uint32_t>(n_paths);
     w.pend = c.take<float4>((size_t)n_paths * nl);
     w.hit = c.take<unsigned long long>(2 * live_total + (size_t)n_paths * nl);
     w.q_o = c.take<float4>(2 * queue_entries);
@@ -294,6 +295,8 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     f.max_depth = opt->max_depth;
     f.count_casts = 0;
     f.prune_zero_terms = 0;
+    // (a frame without bounces has no first bounce to compute the camera rays again)
+    f.regenerate = opt->arithmetic != 0 && opt->max_depth >= 1;
     return f;
 }
 
@@ -828,7 +831,8 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         for (int depth = 0; depth < opt->max_depth; depth++) {
             if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
-            hipLaunchKernelGGL((fast ? k_shade_fast : k_shade), depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
+            if (depth == 0 && f.regenerate) hipLaunchKernelGGL(k_shade_fast_first, grid, block, 0, stream, s->d, w, f);
+            else hipLaunchKernelGGL((fast ? k_shade_fast : k_shade), depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
         }
