@@ -57,6 +57,23 @@ def test_deterministic_modes_agree_per_pixel_within_1e4(scene, bbox):
     assert np.median(inside) < 1e-5
 
 
+@pytest.mark.parametrize("depth", [0, 1, 2])
+@pytest.mark.parametrize("scene", ["mesh_scene", "default"])
+def test_shallow_frames_agree_per_pixel(scene, depth):
+    """Bounce limits of 0, 1 and 2: with the fast arithmetic the first bounce computes the camera rays again instead
+    of reading them back, which a frame without bounces cannot do (its camera kernel writes the path state itself)."""
+    s = load(scene, 160, 120, 3)
+    opts = dict(indirect=True, antialiasing=False, bounding_box=True, max_depth=depth, seed=4)
+    exact = render(s, arithmetic=0, **opts)
+    fast = render(s, arithmetic=1, **opts)
+    if depth == 0:
+        assert not exact.any() and not fast.any()  # no bounce, no light (reference src/raytrace.cu:317: the loop does not run)
+        return
+    out, _ = pixels_outside(fast, exact)
+    # indirect light: a pixel whose path flips a decision draws another direction, so a few more pixels differ than in the direct modes
+    assert out.mean() <= 5e-3, f"{out.sum()} of {out.size} pixels outside 1e-4"
+
+
 CONVERGED = [
     # scene, options, RMSE bound and mean bound in 8-bit levels of the clamped image
     ("default", lambda: load("default", 64, 64, 4096), dict(), 0.25, 0.03),
