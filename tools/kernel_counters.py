@@ -31,6 +31,8 @@ FETCH_X2 = ("k_shade", "k_shade_fast", "k_generate", "k_trace_spheres", "k_bin64
 
 def short(name):
     base = name.split("<")[0]
+    if base == "k_shade_fast_first":  # the first bounce of the fast arithmetic is a kernel of its own: one of the frame's bounce launches
+        return "k_shade_fast"
     if base in ("k_generate", "k_trace_spheres"):  # the arithmetic is a template argument
         return base + ("_fast" if "FastMath" in name else "")
     return base
