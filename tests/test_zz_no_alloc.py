@@ -54,6 +54,9 @@ def test_static_work_area_gives_the_sums_of_rt_accumulate():
     # a scene without a mesh, direct light only, then the exhaustive scan
     both_ways(load("default", 96, 64, 4), rt.make_options(indirect=False, seed=63), 0, 4)
     both_ways(load("mesh_scene", 64, 48, 2), rt.make_options(seed=64, cluster_culling=False), 0, 2)
+    # the fast arithmetic (its first bounce regenerates the camera rays from one more work buffer), with and without a mesh
+    both_ways(load("mesh_scene", 120, 90, 5), rt.make_options(seed=68, arithmetic=1), 1, 5)
+    both_ways(load("default", 96, 64, 4), rt.make_options(seed=69, arithmetic=1), 0, 4)
     # continuing a sum: ranges in sample order add up to the whole
     n = cam.width * cam.height
     whole = DeviceBuffer(4 * n)
