@@ -123,6 +123,9 @@ typedef struct rt_stats {
                                   over launches (profile != 0 only) */
     uint32_t shade_kernel_launches;
     uint32_t reserved;
+    uint64_t path_bounces;     /* (path, bounce) pairs the bounce kernel processed: the paths alive on entry, summed over
+                                  its launches -- the unit its memory traffic scales with (0 for a scene without triangles,
+                                  whose frame is one kernel with the paths in registers) */
 } rt_stats;
 
 /* Device-resident scene plus the work buffers of the frames rendered from it.

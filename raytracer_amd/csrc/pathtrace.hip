@@ -793,6 +793,8 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         HIP_TRY(hipEventRecord(s->frame_begin, stream));
     }
     std::vector<uint32_t> counts(stats ? (size_t)n_counters * kShards * kCountStride : 0);
+    std::vector<uint32_t> live_counts(counts.size());
+    uint64_t path_bounces = 0;
     std::vector<uint32_t> cast_counts(stats ? (size_t)n_counters * kCastShards * kCountStride : 0);
     uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
     uint32_t batches = 0;
@@ -848,6 +850,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         }
         if (stats) { // the counters are reused by the next batch: read them now
             HIP_TRY(hipMemcpyAsync(counts.data(), w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(live_counts.data(), w.live_count, live_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(cast_counts.data(), w.cast_count, cast_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
@@ -855,6 +858,10 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             for (size_t i = 0; i < counts.size(); i += kCountStride) batch_rays += counts[i];
             for (size_t i = 0; i < cast_counts.size(); i += kCountStride) sphere_casts += cast_counts[i];
             mesh_rays += batch_rays;
+            // the first bounce sees every path of the batch, bounce d > 0 the paths on its list
+            if (opt->max_depth > 0) path_bounces += f.n_paths;
+            for (int d = 1; d < opt->max_depth; d++)
+                for (uint32_t shard = 0; shard < kShards; shard++) path_bounces += live_counts[((size_t)d * kShards + shard) * kCountStride];
             if (cull) {
                 for (size_t i = 0; i < cl_words; i += kCountStride) tests += (uint64_t)cl_counts[i] * s->cluster_tris[(i / kCountStride) % s->d.n_clusters];
             } else {
@@ -872,6 +879,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         stats->batches = batches;
         stats->paths = paths;
         stats->mesh_rays = mesh_rays;
+        stats->path_bounces = path_bounces;
         stats->triangle_tests = tests;
         stats->sphere_casts = sphere_casts;
     }

@@ -301,3 +301,10 @@ def test_counted_triangle_tests_and_footprint_of_a_scene_handle():
     print(f"{st.triangle_tests / st.paths:.1f} triangle tests per path, {used / 2**30:.2f} GiB held by the handle")
     assert st.triangle_tests / st.paths == pytest.approx(32.3, rel=0.1)
     assert used < 4 * 2**30
+    # (path, bounce) pairs the bounce kernel processed: every path at the first bounce, fewer and fewer afterwards (a
+    # closed room: paths end when their weight becomes zero or at the fifth bounce) -- 2.9 bounces per path on this frame
+    assert st.paths < st.path_bounces < 5 * st.paths
+    assert st.path_bounces / st.paths == pytest.approx(2.94, abs=0.2)
+    # a frame of one bounce: exactly one pair per path
+    _, st1 = dev.render(cam, rt.make_options(seed=1, max_depth=1))
+    assert st1.path_bounces == st1.paths
