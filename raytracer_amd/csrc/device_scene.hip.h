@@ -37,6 +37,7 @@ constexpr uint32_t kLivePending = 0x80000000u; // in an entry of the live-path l
 constexpr uint32_t F_ALIVE = 1u;   // the path still bounces
 constexpr uint32_t F_PENDING = 2u; // pend[] holds light contributions of the last hit
 constexpr uint32_t F_EARLY = 4u;   // the reference's terminate_early for this sample
+constexpr uint32_t kBounceShift = 8; // flags >> kBounceShift: the path's bounce index (kept by the kernels whose paths run ahead of the launches)
 
 constexpr float PEND_NONE = -2.f;   // slot unused
 constexpr float PEND_ALWAYS = -1.f; // contribution known to be visible
@@ -94,6 +95,7 @@ struct Work {
     float4* q_d;
     uint32_t* q_count; // kShards counters (kCountStride words apart) per k_mesh stage of a batch
     uint32_t* cast_count; // statistics: kCastShards counters (kCountStride words apart) per path kernel of a batch
+    uint32_t* bounce_count; // statistics: kCastShards counters more, right after cast_count's: (path, bounce) pairs of a batch
     uint32_t shard_capacity; // queue entries reserved per shard
     // cluster culling: per stage slot, the queue positions of the rays that touch each cluster
     uint32_t* cl_count;      // n_clusters counters per slot
@@ -507,11 +509,12 @@ __device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, const SceneCa
 // index, which spreads the returning atomics over 64 addresses (one address
 // serialises at well under 200 atomics per microsecond).
 // Returns the queue position of this lane's ray (0 when want == false).
-__device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, bool want, V3 start, V3 ray, uint32_t slot, float cutoff) {
+__device__ __forceinline__ uint32_t wave_shard() { return (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards; }
+
+__device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, uint32_t shard, bool want, V3 start, V3 ray, uint32_t slot, float cutoff) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0) return 0;
     const uint32_t lane = __lane_id();
-    const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
     const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(&w.q_count[(counter * kShards + shard) * kCountStride], (uint32_t)__popcll(mask));
@@ -534,14 +537,13 @@ __device__ __forceinline__ size_t shadow_base(const Work& w) { return 2 * (size_
 // there, and the ray is queued for triangle stage `counter` if it has to walk the mesh (walk_b).
 // A shadow ray (want_a) is queued with it.  The two reservations are issued together by lane 0,
 // so the wavefront waits for one round trip to the counters instead of three.
-__device__ __forceinline__ void finish_bounce(const Work& w, uint32_t counter, bool want_a, V3 start, V3 ray_a, uint32_t slot_a,
+__device__ __forceinline__ void finish_bounce(const Work& w, uint32_t counter, uint32_t shard, bool want_a, V3 start, V3 ray_a, uint32_t slot_a,
                                               float cutoff_a, bool alive, bool walk_b, V3 ray_b, float ts_b, int sid_b, float4 thr,
                                               uint32_t entry) {
     const bool want_b = alive && walk_b;
     const unsigned long long mask_a = __ballot(want_a), mask_b = __ballot(want_b), mask_l = __ballot(alive);
     const uint32_t n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b), n_l = (uint32_t)__popcll(mask_l);
     const uint32_t lane = __lane_id();
-    const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards;
     uint32_t base_q = 0, base_l = 0;
     if (lane == 0) {
         if (n_a + n_b) base_q = atomicAdd(&w.q_count[(counter * kShards + shard) * kCountStride], n_a + n_b);
@@ -577,6 +579,15 @@ __device__ __forceinline__ void add_casts(const Work& w, uint32_t counter, uint3
     if (n && __lane_id() == 0) {
         const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kCastShards;
         atomicAdd(&w.cast_count[((size_t)counter * kCastShards + shard) * kCountStride], n);
+    }
+}
+
+// Statistics: adds n (the wavefront's number of paths that were alive on entry to a bounce) to the batch's count of
+// (path, bounce) pairs.  All lanes pass the same n.
+__device__ __forceinline__ void add_bounces(const Work& w, uint32_t n) {
+    if (n && __lane_id() == 0) {
+        const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kCastShards;
+        atomicAdd(&w.bounce_count[(size_t)shard * kCountStride], n);
     }
 }
 

@@ -223,6 +223,39 @@ __device__ __forceinline__ uint32_t ray_position(const ShardMap& m, uint32_t ray
     return shard * shard_capacity + (active ? r : count - 1);
 }
 
+// The same for entry v of the walk through the shards (block v / kBlock, entry v % kBlock of that block), where the
+// lanes of a wavefront ask for entries of [v_first, v_first + 64): of at most two blocks.  v_first is the same in
+// every lane and so is the flow of control.
+__device__ __forceinline__ uint32_t list_position(const ShardMap& m, uint32_t v_first, uint32_t v, uint32_t shard_capacity, bool& active) {
+    const uint32_t block_a = v_first / kBlock;
+    const uint32_t shard_a = (uint32_t)__popcll(__ballot(m.before <= block_a)) - 1u;
+    const uint32_t shard_b = (uint32_t)__popcll(__ballot(m.before <= block_a + 1u)) - 1u;
+    const bool second = v / kBlock != block_a;
+    const uint32_t shard = second ? shard_b : shard_a;
+    // (every lane takes part in all four exchanges: a lane that sat one out could not be read by the others)
+    const uint32_t first_a = __shfl(m.before, (int)shard_a), first_b = __shfl(m.before, (int)shard_b);
+    const uint32_t count_a = __shfl(m.my_count, (int)shard_a), count_b = __shfl(m.my_count, (int)shard_b);
+    const uint32_t shard_first = second ? first_b : first_a;
+    const uint32_t count = second ? count_b : count_a;
+    const uint32_t r = (v / kBlock - shard_first) * kBlock + v % kBlock;
+    active = r < count;
+    return shard * shard_capacity + (active ? r : 0u);
+}
+
+// Entries of its input that one wavefront of a kernel with paths that stay in their lanes takes (a multiple of 64):
+// long stretches keep the wavefronts full for most of their life, short ones leave enough wavefronts to fill the device.
+#ifndef RT_MAX_STRETCH
+#define RT_MAX_STRETCH 512
+#endif
+#ifndef RT_STRETCH_WAVES
+#define RT_STRETCH_WAVES 16384
+#endif
+constexpr uint32_t kMaxStretch = RT_MAX_STRETCH;
+__host__ __device__ inline uint32_t stretch_of(uint32_t n_in) {
+    const uint32_t want = n_in / (64u * RT_STRETCH_WAVES); // at least 16 384 wavefronts (16 per SIMD)
+    return 64u * (want < 1u ? 1u : want > kMaxStretch / 64u ? kMaxStretch / 64u : want);
+}
+
 // One ray per lane against triangle pairs [first, last): two pairs per trip,
 // two SGPR sets.  Scalar loads return out of order, so the only wait available
 // is "all of them": each set is therefore requested right after an explicit

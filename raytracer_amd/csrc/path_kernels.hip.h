@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t commit_ray(const Work& w, uint32_t counter, 
         w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
         w.hit[p] = kNoHit;
     }
-    return enqueue(w, counter, alive && walk, start, ray, p, ts);
+    return enqueue(w, counter, wave_shard(), alive && walk, start, ray, p, ts);
 }
 
 // Nearest sphere + box test for a freshly generated ray, then commit_ray.
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
                 w.gen[p] = first_dim | (walk ? kGenWalks : 0u);
                 if (walk) w.hit[p] = kNoHit;
             }
-            enqueue(w, 0, alive && walk, start, ray, p, ts);
+            enqueue(w, 0, wave_shard(), alive && walk, start, ray, p, ts);
         } else {
             if (alive) {
                 w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
@@ -398,7 +398,18 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
 // hit leave the same point, so their scans run as one (nearest_sphere_pair).
 // kRegenerate (first bounce only, Frame::regenerate): the camera ray is computed again from what k_generate left in
 // Work::gen instead of being read back.
-template <class M, bool kRegenerate = false>
+// kContinue: a path whose bounce ray cannot meet a triangle (it misses every object box) and that leaves no light term
+// waiting for a shadow ray has nothing to ask of the triangle stage: its next bounce needs no other kernel.  Such a
+// path does not go through memory: it stays in its lane and takes its next bounce at once.  Three quarters of the
+// (path, bounce) pairs of a typical frame are of that kind, and the kernel is bound by the path state it writes and
+// reads.  The lanes that fall free (their path ended, or was written for the triangle stage) take the next paths of
+// the wavefront's own stretch of the input, so that a wavefront stays full until that stretch is used up.  The
+// arithmetic per path is the same in the same order, so the image does not change by a bit.
+// With kContinue `depth` counts the kernels a path has been through rather than its bounces: the paths of one list
+// are at different bounces (each one's index rides in its flags, above kBounceShift), all of them at `depth` or
+// beyond, so max_depth launches still see every path to its end.  A path is written at most once per kernel, always
+// to the list and queue of stage depth + 1, and a wavefront writes at most the paths of its own stretch there.
+template <class M, bool kRegenerate = false, bool kContinue = false>
 __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& w, const Frame& f, int depth) {
     __shared__ SceneCache cache;
     __shared__ float4 eye_oc[kRegenerate ? kSphereCache : 1];
@@ -411,35 +422,75 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     uint32_t index = p;
     bool pending = false;
-    if (depth > 0) {
-        const ShardMap map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
-        if (blockIdx.x >= map.n_ray_blocks) return; // the whole workgroup
-        bool active;
-        index = (uint32_t)(depth & 1) * w.live_total + ray_position(map, blockIdx.x, w.live_capacity, active);
-        const uint32_t entry = active ? w.live[index] : 0xffffffffu;
-        p = active ? (entry & ~kLivePending) : 0xffffffffu;
-        pending = active && (entry & kLivePending) != 0;
+    ShardMap map = {0, 0, 0};
+    uint32_t cursor = 0, cursor_end = 0; // kContinue: the wavefront's stretch of the input, in entries of the walk through the shards
+    if constexpr (!kContinue) {
+        if (depth > 0) {
+            map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
+            if (blockIdx.x >= map.n_ray_blocks) return; // the whole workgroup
+            bool active;
+            index = (uint32_t)(depth & 1) * w.live_total + ray_position(map, blockIdx.x, w.live_capacity, active);
+            const uint32_t entry = active ? w.live[index] : 0xffffffffu;
+            p = active ? (entry & ~kLivePending) : 0xffffffffu;
+            pending = active && (entry & kLivePending) != 0;
+        }
+    } else {
+        uint32_t n_in = f.n_paths;
+        if (depth > 0) {
+            map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
+            n_in = map.n_ray_blocks * kBlock;
+        }
+        const uint32_t stretch = stretch_of(n_in);
+        const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+        if ((size_t)blockIdx.x * kWavesPerBlock * stretch >= n_in) return; // the whole workgroup
+        const size_t first = (size_t)wave * stretch;
+        cursor = (uint32_t)(first < n_in ? first : n_in);
+        cursor_end = (uint32_t)(first + stretch < n_in ? first + stretch : n_in);
+        p = 0xffffffffu;
     }
     stage_scene(sc, cache);
     if constexpr (kRegenerate) {
         stage_eye<M>(sc, cache, f, eye_oc);
         __syncthreads();
     }
+    // the path's state on entry: colour and flags, ray (origin + nearest-sphere distance, direction + sphere index),
+    // weight + next random dimension, the triangle stage's answer; read from memory, computed again (kRegenerate) or
+    // handed over by the previous trip of the loop below (kContinue)
+    float4 rad = make_float4(0.f, 0.f, 0.f, 0.f), ro4 = rad, rd4 = rad, th = rad;
+    unsigned long long key = kNoHit;
+    float4 first_pend = make_float4(0.f, 0.f, 0.f, PEND_NONE);
+    unsigned long long first_key = kNoHit;
     const uint32_t counter = (uint32_t)depth + 1u;
-    bool alive = false; // the path continues with a bounce ray
-    bool lit = false;   // diffuse hit: the lights are evaluated at `start`
-    bool open = false;  // the path was alive on entry: its radiance record is rewritten
-    V3 start = mk(0, 0, 0), ray = mk(0, 0, 1);
-    V3 P = mk(0, 0, 0), N = mk(0, 0, 1), L = mk(0, 0, 0);
-    V3 weight = mk(0, 0, 0), colour = mk(0, 0, 0); // path weight before this hit, surface colour
-    uint32_t flags = 0;
-    uint32_t next_dim = 0;     // next random dimension of the path after this bounce
-    bool tinted = false;       // the weight after this bounce is weight * colour (diffuse hit with indirect light)
-    if (p < f.n_paths) {
-        float4 rad, ro4, rd4, th;
-        unsigned long long key = kNoHit;
-        float4 first_pend = make_float4(0.f, 0.f, 0.f, PEND_NONE);
-        unsigned long long first_key = kNoHit;
+    const uint32_t shard = wave_shard();
+    bool fresh = p < f.n_paths; // the lane has to fetch its path's state
+    for (;;) { // (one trip unless kContinue)
+    if constexpr (kContinue) {
+        // the free lanes take the next entries of the stretch, in lane order
+        const unsigned long long free_lanes = __ballot(p >= f.n_paths);
+        const uint32_t left = cursor_end - cursor, n_free = (uint32_t)__popcll(free_lanes);
+        const uint32_t n_take = n_free < left ? n_free : left;
+        const uint32_t rank = (uint32_t)__popcll(free_lanes & ((1ULL << __lane_id()) - 1ULL));
+        const bool take = p >= f.n_paths && rank < n_take;
+        if (depth == 0) {
+            if (take) p = index = cursor + rank;
+        } else if (n_take) {
+            bool active;
+            const uint32_t at = list_position(map, cursor, cursor + rank, w.live_capacity, active);
+            if (take) {
+                index = (uint32_t)(depth & 1) * w.live_total + at;
+                const uint32_t entry = active ? w.live[index] : 0xffffffffu;
+                p = active ? (entry & ~kLivePending) : 0xffffffffu;
+                pending = active && (entry & kLivePending) != 0;
+            }
+        }
+        cursor += n_take;
+        if (__ballot(p < f.n_paths) == 0ULL) {
+            if (cursor == cursor_end) break; // (the whole wavefront)
+            continue; // (entries past the end of a shard's last block)
+        }
+        fresh = take && p < f.n_paths;
+    }
+    if (fresh) {
         if constexpr (kRegenerate) {
             const uint32_t g = w.gen[p];
             if (g & kGenWalks) key = w.hit[p];
@@ -464,9 +515,29 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
                 first_key = w.hit[shadow_base(w) + (size_t)p * sc.n_lights];
             }
         }
+    }
+    bool alive = false; // the path continues with a bounce ray
+    bool lit = false;   // diffuse hit: the lights are evaluated at `start`
+    bool open = false;  // the path was alive on entry: its radiance record is rewritten
+    V3 start = mk(0, 0, 0), ray = mk(0, 0, 1);
+    V3 P = mk(0, 0, 0), N = mk(0, 0, 1), L = mk(0, 0, 0);
+    V3 weight = mk(0, 0, 0), colour = mk(0, 0, 0); // path weight before this hit, surface colour
+    uint32_t flags = 0;
+    uint32_t next_dim = 0;     // next random dimension of the path after this bounce
+    bool tinted = false;       // the weight after this bounce is weight * colour (diffuse hit with indirect light)
+    float ts = INFINITY;       // the bounce ray's nearest sphere
+    int sid = -1;
+    bool at_once = false;      // the path goes on at once, in this kernel: nothing of it is written
+    float4 next_thr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < f.n_paths) {
         flags = __float_as_uint(rad.w);
         if (flags & F_ALIVE) {
             open = true;
+            int bounce = depth;
+            if constexpr (kContinue) {
+                bounce = (int)(flags >> kBounceShift);
+                flags += 1u << kBounceShift;
+            }
             L = mk(rad.x, rad.y, rad.z);
             if (flags & F_PENDING) {
                 L = settle_pending(sc, w, f.n_paths, p, L, pending, first_pend, first_key);
@@ -503,15 +574,13 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
                 weight = xyz(th);
                 uint32_t dim = __float_as_uint(th.w);
                 const rt_rng_key rng = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
-                respond_to_hit<M>(sc, cache, f, rng, depth, m, P, N, start, ray, weight, colour, dim, flags, alive, lit, tinted);
+                respond_to_hit<M>(sc, cache, f, rng, bounce, m, P, N, start, ray, weight, colour, dim, flags, alive, lit, tinted);
                 next_dim = dim;
             }
         }
     }
 
     // ---- shared part: shadow rays of diffuse hits, then the bounce ray ----
-    float ts = INFINITY;
-    int sid = -1;
     bool walk = false;
     bool bounce_probed = false;
     bool deferred = false;
@@ -586,7 +655,7 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
             }
         }
         if (l + 1 < sc.n_lights) {
-            enqueue(w, counter, lit && shadow_walk, start, sray, (uint32_t)(shadow_base(w) + slot), dist);
+            enqueue(w, counter, shard, lit && shadow_walk, start, sray, (uint32_t)(shadow_base(w) + slot), dist);
         } else {
             last_want = lit && shadow_walk;
             last_sray = sray;
@@ -594,21 +663,44 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
             last_slot = (uint32_t)(shadow_base(w) + slot);
         }
     }
-    if (f.count_casts)
+    if (f.count_casts) {
         add_casts(w, counter, (uint32_t)__popcll(__ballot(lit)) * sc.n_lights + (uint32_t)__popcll(__ballot(alive)));
-    if (deferred) flags |= F_PENDING;
-    if (open) {
-        if (!alive) flags &= ~F_ALIVE;
-        w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
+        add_bounces(w, (uint32_t)__popcll(__ballot(open)));
     }
+    if (deferred) flags |= F_PENDING;
     if (!bounce_probed && alive) { // a scene without lights
         ts = nearest_sphere<M>(sc, cache, ray, start, sid);
         walk = needs_mesh<false, M>(sc, cache, f.bounding_box, ray, start);
     }
+    at_once = kContinue && alive && !walk && !deferred;
+#ifdef RT_DBG_ATONCE
+    if (RT_DBG_ATONCE == 1) at_once = false;
+    if (RT_DBG_ATONCE == 2 && depth != 0) at_once = false;
+    if (RT_DBG_ATONCE == 3 && depth == 0) at_once = false;
+    if (RT_DBG_ATONCE == 4 && !fresh) at_once = false;
+#endif
+    if (open && !at_once) {
+        if (!alive) flags &= ~F_ALIVE;
+        w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
+    }
     // (the product again rather than three registers kept across the lights: same operands, same bits)
     const V3 next_weight = tinted ? weight * colour : weight;
-    finish_bounce(w, counter, last_want, start, last_sray, last_slot, last_dist, alive, walk, ray, ts, sid,
-                  make_float4(next_weight.x, next_weight.y, next_weight.z, __uint_as_float(next_dim)), p | (deferred ? kLivePending : 0u));
+    next_thr = make_float4(next_weight.x, next_weight.y, next_weight.z, __uint_as_float(next_dim));
+    finish_bounce(w, counter, shard, last_want, start, last_sray, last_slot, last_dist, alive && !at_once, walk, ray, ts, sid,
+                  next_thr, p | (deferred ? kLivePending : 0u));
+    if constexpr (!kContinue) {
+        break;
+    } else {
+        // a path that goes on at once keeps its lane; the others' lanes are free
+        rad = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
+        ro4 = make_float4(start.x, start.y, start.z, ts);
+        rd4 = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
+        th = next_thr;
+        key = kNoHit; // no triangle can be met: the ray misses every object box
+        pending = false;
+        if (!at_once) p = 0xffffffffu;
+    }
+    } // trips
 }
 
 // (At least five wavefronts per SIMD: 96 VGPRs.  One register more would cost a fifth of the occupancy.)
@@ -616,14 +708,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     shade_bounce<ExactMath>(sc, w, f, depth);
 }
 
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 5
+#endif
 // rt_options.arithmetic = 1
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast(DeviceScene sc, Work w, Frame f, int depth) {
-    shade_bounce<FastMath>(sc, w, f, depth);
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, 8))) void k_shade_fast(DeviceScene sc, Work w, Frame f, int depth) {
+    shade_bounce<FastMath, false, true>(sc, w, f, depth);
 }
 
 // ... and its first bounce when the camera rays are regenerated (Frame::regenerate)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast_first(DeviceScene sc, Work w, Frame f) {
-    shade_bounce<FastMath, true>(sc, w, f, 0);
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, 8))) void k_shade_fast_first(DeviceScene sc, Work w, Frame f) {
+    shade_bounce<FastMath, true, true>(sc, w, f, 0);
+}
+
+// (development: the exact arithmetic with paths that go on at once, to check against the oracle bit for bit)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_continue(DeviceScene sc, Work w, Frame f, int depth) {
+    shade_bounce<ExactMath, false, true>(sc, w, f, depth);
 }
 
 // ---- scenes without triangles: the whole sample loop in registers -------

@@ -193,9 +193,12 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     // a shard receives the rays of every kShards-th wavefront of a path kernel
     // (k_shade walks its list of live paths shard by shard, every shard ending in a partial workgroup:
     // up to kShards workgroups more than the paths need)
-    const size_t n_waves = (((size_t)n_paths + kBlock - 1) / kBlock + kShards) * kWavesPerBlock;
+    // (or of every kShards-th workgroup of the kernels that reserve by workgroup: what is reserved here covers both)
+    const size_t n_groups_of_paths = ((size_t)n_paths + kBlock - 1) / kBlock + kShards;
+    // (a wavefront of those kernels takes up to kMaxStretch paths; with w wavefronts launched a shard serves ceil(w / kShards))
+    const size_t per_shard = ((n_groups_of_paths + kShards - 1) / kShards) * kBlock + 2 * kMaxStretch;
     // k_shade: a wavefront queues at most 64 * (1 + lights) rays; k_generate: 64 * kGenPaths, from fewer wavefronts
-    size_t shard_capacity = ((n_waves + kShards - 1) / kShards) * 64 * (1 + nl);
+    size_t shard_capacity = per_shard * (1 + nl);
     for (size_t r = 2; r <= kGenPaths; r *= 2) {
         const size_t gen_waves = (((size_t)n_paths + kBlock * r - 1) / (kBlock * r)) * kWavesPerBlock;
         shard_capacity = std::max(shard_capacity, ((gen_waves + kShards - 1) / kShards) * 64 * r);
@@ -217,7 +220,7 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     const size_t slots_cl = (size_t)n_counters * tiles;
     const size_t q_words = (size_t)n_counters * kShards * kCountStride;
     const size_t cl_words = slots_cl * nc * kCountStride, grp_words = slots_cl * ng * kCountStride;
-    const size_t live_capacity = ((n_waves + kShards - 1) / kShards) * 64; // a wavefront keeps at most its 64 paths
+    const size_t live_capacity = per_shard; // a wavefront keeps at most its 64 paths, a workgroup its 256
     const size_t live_total = kShards * live_capacity; // >= n_paths: buffer 0 also holds the camera rays at the paths' own indices
     if (2 * live_total + (size_t)n_paths * nl > 0xffffffffu) { rt_set_error("batch too large for 32-bit hit slots"); return RT_ERR_INVALID; }
     Carver c{arena};
@@ -237,7 +240,8 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     w.cl_count = w.live_count + q_words;
     w.grp_count = w.cl_count + cl_words;
     w.live = c.take<uint32_t>(2 * kShards * live_capacity);
-    w.cast_count = c.take<uint32_t>((size_t)n_counters * kCastShards * kCountStride);
+    w.cast_count = c.take<uint32_t>((size_t)(n_counters + 1) * kCastShards * kCountStride);
+    w.bounce_count = w.cast_count + (size_t)n_counters * kCastShards * kCountStride;
     w.cl_list = c.take<uint32_t>(lists_nc * list_capacity);
     w.grp_list = c.take<uint32_t>(ng * list_capacity);
     w.live_total = (uint32_t)live_total;
@@ -296,7 +300,7 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     f.count_casts = 0;
     f.prune_zero_terms = 0;
     // (a frame without bounces has no first bounce to compute the camera rays again)
-    f.regenerate = opt->arithmetic != 0 && opt->max_depth >= 1;
+    f.regenerate = false && opt->arithmetic != 0 && opt->max_depth >= 1;
     return f;
 }
 
@@ -793,7 +797,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         HIP_TRY(hipEventRecord(s->frame_begin, stream));
     }
     std::vector<uint32_t> counts(stats ? (size_t)n_counters * kShards * kCountStride : 0);
-    std::vector<uint32_t> live_counts(counts.size());
+    std::vector<uint32_t> bounce_counts(stats ? (size_t)kCastShards * kCountStride : 0);
     uint64_t path_bounces = 0;
     std::vector<uint32_t> cast_counts(stats ? (size_t)n_counters * kCastShards * kCountStride : 0);
     uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
@@ -820,7 +824,10 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
                 if (s->d.n_groups) HIP_TRY(hipMemsetAsync(w.grp_count, 0, slots * s->d.n_groups, stream));
             }
         }
-        if (stats) HIP_TRY(hipMemsetAsync(w.cast_count, 0, cast_counts.size() * sizeof(uint32_t), stream));
+        if (stats) {
+            HIP_TRY(hipMemsetAsync(w.cast_count, 0, cast_counts.size() * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(w.bounce_count, 0, bounce_counts.size() * sizeof(uint32_t), stream));
+        }
         // paths per lane: as many as still leave 2 048 workgroups (8 per CU)
         const bool fast = opt->arithmetic != 0;
         if (f.n_paths >= 2048u * kBlock * 4)
@@ -834,7 +841,14 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
             if (depth == 0 && f.regenerate) hipLaunchKernelGGL(k_shade_fast_first, grid, block, 0, stream, s->d, w, f);
-            else hipLaunchKernelGGL((fast ? k_shade_fast : k_shade), depth == 0 ? grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
+            else {
+                static const bool exact_continue = std::getenv("RT_AMD_EXACT_CONTINUE") != nullptr; // development knob
+                // (the kernels whose paths stay in their lanes: a wavefront takes stretch_of() paths; how many the lists
+                // of the later launches hold is not known here)
+                const bool stays = fast || exact_continue;
+                const dim3 first_grid = stays ? dim3((f.n_paths + kWavesPerBlock * stretch_of(f.n_paths) - 1) / (kWavesPerBlock * stretch_of(f.n_paths))) : grid;
+                hipLaunchKernelGGL((fast ? k_shade_fast : exact_continue ? k_shade_continue : k_shade), depth == 0 ? first_grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
+            }
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
         }
@@ -850,7 +864,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         }
         if (stats) { // the counters are reused by the next batch: read them now
             HIP_TRY(hipMemcpyAsync(counts.data(), w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipMemcpyAsync(live_counts.data(), w.live_count, live_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(bounce_counts.data(), w.bounce_count, bounce_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(cast_counts.data(), w.cast_count, cast_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
@@ -858,10 +872,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             for (size_t i = 0; i < counts.size(); i += kCountStride) batch_rays += counts[i];
             for (size_t i = 0; i < cast_counts.size(); i += kCountStride) sphere_casts += cast_counts[i];
             mesh_rays += batch_rays;
-            // the first bounce sees every path of the batch, bounce d > 0 the paths on its list
-            if (opt->max_depth > 0) path_bounces += f.n_paths;
-            for (int d = 1; d < opt->max_depth; d++)
-                for (uint32_t shard = 0; shard < kShards; shard++) path_bounces += live_counts[((size_t)d * kShards + shard) * kCountStride];
+            for (size_t i = 0; i < bounce_counts.size(); i += kCountStride) path_bounces += bounce_counts[i];
             if (cull) {
                 for (size_t i = 0; i < cl_words; i += kCountStride) tests += (uint64_t)cl_counts[i] * s->cluster_tris[(i / kCountStride) % s->d.n_clusters];
             } else {
