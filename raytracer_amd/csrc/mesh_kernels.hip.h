@@ -224,19 +224,20 @@ __device__ __forceinline__ uint32_t ray_position(const ShardMap& m, uint32_t ray
 }
 
 // The same for entry v of the walk through the shards (block v / kBlock, entry v % kBlock of that block), where the
-// lanes of a wavefront ask for entries of [v_first, v_first + 64): of at most two blocks.  v_first is the same in
-// every lane and so is the flow of control.
-__device__ __forceinline__ uint32_t list_position(const ShardMap& m, uint32_t v_first, uint32_t v, uint32_t shard_capacity, bool& active) {
+// lanes of a wavefront ask for entries of [v_first, v_first + 64): of at most two blocks.  The map is read from LDS
+// (what lane l of load_shard_map holds at [l]) rather than kept in two registers of a kernel that has none to spare.
+// v_first is the same in every lane and so is the flow of control.
+struct ShardTable {
+    uint32_t count[kShards], before[kShards];
+};
+__device__ __forceinline__ uint32_t list_position(const ShardTable& t, uint32_t v_first, uint32_t v, uint32_t shard_capacity, bool& active) {
     const uint32_t block_a = v_first / kBlock;
-    const uint32_t shard_a = (uint32_t)__popcll(__ballot(m.before <= block_a)) - 1u;
-    const uint32_t shard_b = (uint32_t)__popcll(__ballot(m.before <= block_a + 1u)) - 1u;
+    const uint32_t mine = t.before[__lane_id()];
+    const uint32_t shard_a = (uint32_t)__popcll(__ballot(mine <= block_a)) - 1u; // `before` is non-decreasing
+    const uint32_t shard_b = (uint32_t)__popcll(__ballot(mine <= block_a + 1u)) - 1u;
     const bool second = v / kBlock != block_a;
     const uint32_t shard = second ? shard_b : shard_a;
-    // (every lane takes part in all four exchanges: a lane that sat one out could not be read by the others)
-    const uint32_t first_a = __shfl(m.before, (int)shard_a), first_b = __shfl(m.before, (int)shard_b);
-    const uint32_t count_a = __shfl(m.my_count, (int)shard_a), count_b = __shfl(m.my_count, (int)shard_b);
-    const uint32_t shard_first = second ? first_b : first_a;
-    const uint32_t count = second ? count_b : count_a;
+    const uint32_t shard_first = t.before[shard], count = t.count[shard];
     const uint32_t r = (v / kBlock - shard_first) * kBlock + v % kBlock;
     active = r < count;
     return shard * shard_capacity + (active ? r : 0u);
@@ -244,17 +245,13 @@ __device__ __forceinline__ uint32_t list_position(const ShardMap& m, uint32_t v_
 
 // Entries of its input that one wavefront of a kernel with paths that stay in their lanes takes (a multiple of 64):
 // long stretches keep the wavefronts full for most of their life, short ones leave enough wavefronts to fill the device.
-#ifndef RT_MAX_STRETCH
-#define RT_MAX_STRETCH 512
-#endif
-#ifndef RT_STRETCH_WAVES
-#define RT_STRETCH_WAVES 16384
-#endif
-constexpr uint32_t kMaxStretch = RT_MAX_STRETCH;
-__host__ __device__ inline uint32_t stretch_of(uint32_t n_in) {
-    const uint32_t want = n_in / (64u * RT_STRETCH_WAVES); // at least 16 384 wavefronts (16 per SIMD)
+constexpr uint32_t kMaxStretch = 512;
+__host__ __device__ inline uint32_t stretch_of(uint32_t n_in, uint32_t min_waves) {
+    const uint32_t want = n_in / (64u * min_waves);
     return 64u * (want < 1u ? 1u : want > kMaxStretch / 64u ? kMaxStretch / 64u : want);
 }
+// (Measured on the 8.4 M paths of the headline frame, stretches of 256 / 512 / 1 024: 4 690 / 4 795 / 4 733 Mpaths/s.)
+constexpr uint32_t kMinStretchWaves = 16384; // 16 wavefronts per SIMD
 
 // One ray per lane against triangle pairs [first, last): two pairs per trip,
 // two SGPR sets.  Scalar loads return out of order, so the only wait available

@@ -19,7 +19,7 @@ struct Frame {
     uint32_t seed;
     int32_t indirect, antialiasing, bounding_box, max_depth;
     int32_t count_casts;    // count the rays tested against the spheres (statistics)
-    int32_t regenerate;     // k_generate leaves (accepted draw, walks the mesh) per path instead of the ray, and the first
+    uint32_t min_waves;     // kernels whose paths stay in their lanes: the fewest wavefronts a long input is spread over (stretch_of)
                             // bounce computes the camera ray again: 136 bytes of state per path that make no round trip
                             // through memory, for some 150 instructions more in a kernel that is short of bandwidth,
                             // not of issue slots (fast arithmetic only: there the two kernels compute the same bits
@@ -215,14 +215,14 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
         const bool alive = p < f.n_paths;
         V3 start = mk(f.pos[0], f.pos[1], f.pos[2]);
         V3 ray = mk(0.f, 0.f, 1.f);
-        uint32_t first_dim = 0, dim = 0;
+        uint32_t dim = 0;
         if (alive) {
             const uint32_t pixel = path_pixel(f, p);
             const uint32_t ux = pixel % f.width, uy = pixel / f.width;
             rt_rng_key key;
             key.kp = key_kp[r][threadIdx.x];
             key.ks = key_ks[r][threadIdx.x];
-            first_dim = dim = f.antialiasing ? accepted[r][threadIdx.x] : 0u;
+            dim = f.antialiasing ? accepted[r][threadIdx.x] : 0u;
             ray = camera_ray<M>(f, key, ux, uy, dim);
         }
         int sid = -1;
@@ -232,19 +232,11 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             ts = nearest_sphere_from_eye<M>(sc, cache, eye_oc, start, ray, sid);
             walk = needs_mesh<true, M>(sc, cache, f.bounding_box, ray, start);
         }
-        if (f.regenerate) { // the first bounce computes the ray again: it needs the accepted draw and, if the ray walks the mesh, a hit slot
-            if (alive) {
-                w.gen[p] = first_dim | (walk ? kGenWalks : 0u);
-                if (walk) w.hit[p] = kNoHit;
-            }
-            enqueue(w, 0, wave_shard(), alive && walk, start, ray, p, ts);
-        } else {
-            if (alive) {
-                w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
-                w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
-            }
-            commit_ray(w, 0, alive, p, start, ray, ts, sid, walk);
+        if (alive) {
+            w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
+            w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
         }
+        commit_ray(w, 0, alive, p, start, ray, ts, sid, walk);
         n_casts += (uint32_t)__popcll(__ballot(alive));
     }
     if (f.count_casts) add_casts(w, 0, n_casts);
@@ -396,8 +388,6 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
 // the sphere scans and box tests of the shadow rays (diffuse hits) and of the
 // bounce ray.  The first light's shadow ray and the bounce ray of a diffuse
 // hit leave the same point, so their scans run as one (nearest_sphere_pair).
-// kRegenerate (first bounce only, Frame::regenerate): the camera ray is computed again from what k_generate left in
-// Work::gen instead of being read back.
 // kContinue: a path whose bounce ray cannot meet a triangle (it misses every object box) and that leaves no light term
 // waiting for a shadow ray has nothing to ask of the triangle stage: its next bounce needs no other kernel.  Such a
 // path does not go through memory: it stays in its lane and takes its next bounce at once.  Three quarters of the
@@ -409,10 +399,9 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
 // are at different bounces (each one's index rides in its flags, above kBounceShift), all of them at `depth` or
 // beyond, so max_depth launches still see every path to its end.  A path is written at most once per kernel, always
 // to the list and queue of stage depth + 1, and a wavefront writes at most the paths of its own stretch there.
-template <class M, bool kRegenerate = false, bool kContinue = false>
+template <class M, bool kContinue = false>
 __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& w, const Frame& f, int depth) {
     __shared__ SceneCache cache;
-    __shared__ float4 eye_oc[kRegenerate ? kSphereCache : 1];
     // The first bounce sees every path; later ones walk the list of paths the previous bounce
     // left alive, so that the lanes of a wavefront are all busy however many paths have ended.
     // A list entry is the path index, with kLivePending set when light terms of the previous
@@ -422,11 +411,11 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     uint32_t index = p;
     bool pending = false;
-    ShardMap map = {0, 0, 0};
+    __shared__ ShardTable table; // kContinue: the shards of the input list
     uint32_t cursor = 0, cursor_end = 0; // kContinue: the wavefront's stretch of the input, in entries of the walk through the shards
     if constexpr (!kContinue) {
         if (depth > 0) {
-            map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
+            const ShardMap map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
             if (blockIdx.x >= map.n_ray_blocks) return; // the whole workgroup
             bool active;
             index = (uint32_t)(depth & 1) * w.live_total + ray_position(map, blockIdx.x, w.live_capacity, active);
@@ -437,10 +426,14 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
     } else {
         uint32_t n_in = f.n_paths;
         if (depth > 0) {
-            map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
+            const ShardMap map = load_shard_map(w.live_count + (size_t)depth * kShards * kCountStride);
             n_in = map.n_ray_blocks * kBlock;
+            if (threadIdx.x < kShards) { // (stage_scene's barrier comes before the first use)
+                table.count[threadIdx.x] = map.my_count;
+                table.before[threadIdx.x] = map.before;
+            }
         }
-        const uint32_t stretch = stretch_of(n_in);
+        const uint32_t stretch = stretch_of(n_in, f.min_waves);
         const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
         if ((size_t)blockIdx.x * kWavesPerBlock * stretch >= n_in) return; // the whole workgroup
         const size_t first = (size_t)wave * stretch;
@@ -449,21 +442,18 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         p = 0xffffffffu;
     }
     stage_scene(sc, cache);
-    if constexpr (kRegenerate) {
-        stage_eye<M>(sc, cache, f, eye_oc);
-        __syncthreads();
-    }
     // the path's state on entry: colour and flags, ray (origin + nearest-sphere distance, direction + sphere index),
-    // weight + next random dimension, the triangle stage's answer; read from memory, computed again (kRegenerate) or
-    // handed over by the previous trip of the loop below (kContinue)
+    // weight + next random dimension, the triangle stage's answer; read from memory or kept from the previous trip of
+    // the loop below (kContinue)
     float4 rad = make_float4(0.f, 0.f, 0.f, 0.f), ro4 = rad, rd4 = rad, th = rad;
     unsigned long long key = kNoHit;
-    float4 first_pend = make_float4(0.f, 0.f, 0.f, PEND_NONE);
-    unsigned long long first_key = kNoHit;
     const uint32_t counter = (uint32_t)depth + 1u;
     const uint32_t shard = wave_shard();
     bool fresh = p < f.n_paths; // the lane has to fetch its path's state
     for (;;) { // (one trip unless kContinue)
+    uint32_t at_index = index; // where the state of a path that is fetched lies
+    float4 first_pend = make_float4(0.f, 0.f, 0.f, PEND_NONE); // (fetched with the state: the first light term that waits, its shadow ray's answer)
+    unsigned long long first_key = kNoHit;
     if constexpr (kContinue) {
         // the free lanes take the next entries of the stretch, in lane order
         const unsigned long long free_lanes = __ballot(p >= f.n_paths);
@@ -472,13 +462,13 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         const uint32_t rank = (uint32_t)__popcll(free_lanes & ((1ULL << __lane_id()) - 1ULL));
         const bool take = p >= f.n_paths && rank < n_take;
         if (depth == 0) {
-            if (take) p = index = cursor + rank;
+            if (take) p = at_index = cursor + rank;
         } else if (n_take) {
             bool active;
-            const uint32_t at = list_position(map, cursor, cursor + rank, w.live_capacity, active);
+            const uint32_t at = list_position(table, cursor, cursor + rank, w.live_capacity, active);
             if (take) {
-                index = (uint32_t)(depth & 1) * w.live_total + at;
-                const uint32_t entry = active ? w.live[index] : 0xffffffffu;
+                at_index = (uint32_t)(depth & 1) * w.live_total + at;
+                const uint32_t entry = active ? w.live[at_index] : 0xffffffffu;
                 p = active ? (entry & ~kLivePending) : 0xffffffffu;
                 pending = active && (entry & kLivePending) != 0;
             }
@@ -491,25 +481,11 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         fresh = take && p < f.n_paths;
     }
     if (fresh) {
-        if constexpr (kRegenerate) {
-            const uint32_t g = w.gen[p];
-            if (g & kGenWalks) key = w.hit[p];
-            const uint32_t pixel = path_pixel(f, p);
-            const uint32_t ux = pixel % f.width, uy = pixel / f.width;
-            uint32_t dim = g & ~kGenWalks;
-            const V3 eye = mk(f.pos[0], f.pos[1], f.pos[2]);
-            const V3 cray = camera_ray<M>(f, rt_rng_make_key(f.seed, pixel, path_sample(f, p)), ux, uy, dim);
-            int csid;
-            const float cts = nearest_sphere_from_eye<M>(sc, cache, eye_oc, eye, cray, csid);
-            rad = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
-            th = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
-            ro4 = make_float4(eye.x, eye.y, eye.z, cts);
-            rd4 = make_float4(cray.x, cray.y, cray.z, __int_as_float(csid));
-        } else {
+        {
             // the whole state of the path in one round trip to memory
             rad = w.rad[p];
-            ro4 = w.ray_o[index], rd4 = w.ray_d[index], th = w.thr[index];
-            key = w.hit[index];
+            ro4 = w.ray_o[at_index], rd4 = w.ray_d[at_index], th = w.thr[at_index];
+            key = w.hit[at_index];
             if (pending) {
                 first_pend = w.pend[(size_t)p * sc.n_lights];
                 first_key = w.hit[shadow_base(w) + (size_t)p * sc.n_lights];
@@ -673,12 +649,6 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         walk = needs_mesh<false, M>(sc, cache, f.bounding_box, ray, start);
     }
     at_once = kContinue && alive && !walk && !deferred;
-#ifdef RT_DBG_ATONCE
-    if (RT_DBG_ATONCE == 1) at_once = false;
-    if (RT_DBG_ATONCE == 2 && depth != 0) at_once = false;
-    if (RT_DBG_ATONCE == 3 && depth == 0) at_once = false;
-    if (RT_DBG_ATONCE == 4 && !fresh) at_once = false;
-#endif
     if (open && !at_once) {
         if (!alive) flags &= ~F_ALIVE;
         w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
@@ -708,22 +678,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     shade_bounce<ExactMath>(sc, w, f, depth);
 }
 
-#ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 5
-#endif
 // rt_options.arithmetic = 1
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, 8))) void k_shade_fast(DeviceScene sc, Work w, Frame f, int depth) {
-    shade_bounce<FastMath, false, true>(sc, w, f, depth);
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast(DeviceScene sc, Work w, Frame f, int depth) {
+    shade_bounce<FastMath, true>(sc, w, f, depth);
 }
 
-// ... and its first bounce when the camera rays are regenerated (Frame::regenerate)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, 8))) void k_shade_fast_first(DeviceScene sc, Work w, Frame f) {
-    shade_bounce<FastMath, true, true>(sc, w, f, 0);
-}
-
-// (development: the exact arithmetic with paths that go on at once, to check against the oracle bit for bit)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_continue(DeviceScene sc, Work w, Frame f, int depth) {
-    shade_bounce<ExactMath, false, true>(sc, w, f, depth);
+// The control flow of k_shade_fast with the arithmetic of k_shade: what the tests hold against the oracle bit for bit
+// (RT_AMD_EXACT_STAYS, a validation knob; slower than k_shade, which has the registers for one trip only).
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_stays(DeviceScene sc, Work w, Frame f, int depth) {
+    shade_bounce<ExactMath, true>(sc, w, f, depth);
 }
 
 // ---- scenes without triangles: the whole sample loop in registers -------

@@ -230,7 +230,6 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     w.ray_d.base = rays + 1;
     w.thr = c.take<float4>(2 * live_total);
     w.rad = c.take<float4>(n_paths);
-    w.gen = c.take<uint32_t>(n_paths);
     w.pend = c.take<float4>((size_t)n_paths * nl);
     w.hit = c.take<unsigned long long>(2 * live_total + (size_t)n_paths * nl);
     w.q_o = c.take<float4>(2 * queue_entries);
@@ -300,7 +299,9 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     f.count_casts = 0;
     f.prune_zero_terms = 0;
     // (a frame without bounces has no first bounce to compute the camera rays again)
-    f.regenerate = false && opt->arithmetic != 0 && opt->max_depth >= 1;
+    // (validation knob: short stretches are what small frames get; RT_AMD_STRETCH_WAVES=1 gives them long ones)
+    static const int stretch_waves = [] { const char* e = std::getenv("RT_AMD_STRETCH_WAVES"); return e ? std::atoi(e) : 0; }();
+    f.min_waves = stretch_waves > 0 ? (uint32_t)stretch_waves : kMinStretchWaves;
     return f;
 }
 
@@ -840,14 +841,15 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         for (int depth = 0; depth < opt->max_depth; depth++) {
             if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
-            if (depth == 0 && f.regenerate) hipLaunchKernelGGL(k_shade_fast_first, grid, block, 0, stream, s->d, w, f);
-            else {
-                static const bool exact_continue = std::getenv("RT_AMD_EXACT_CONTINUE") != nullptr; // development knob
-                // (the kernels whose paths stay in their lanes: a wavefront takes stretch_of() paths; how many the lists
-                // of the later launches hold is not known here)
-                const bool stays = fast || exact_continue;
-                const dim3 first_grid = stays ? dim3((f.n_paths + kWavesPerBlock * stretch_of(f.n_paths) - 1) / (kWavesPerBlock * stretch_of(f.n_paths))) : grid;
-                hipLaunchKernelGGL((fast ? k_shade_fast : exact_continue ? k_shade_continue : k_shade), depth == 0 ? first_grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
+            {
+                // The kernels whose paths stay in their lanes: a wavefront takes stretch_of() paths; how many the lists
+                // of the later launches hold is not known here.
+                // (RT_AMD_EXACT_STAYS: that control flow with the exact arithmetic, for the tests against the oracle.)
+                static const bool exact_stays = std::getenv("RT_AMD_EXACT_STAYS") != nullptr;
+                const bool stays = fast || exact_stays;
+                const uint32_t per_group = kWavesPerBlock * stretch_of(f.n_paths, f.min_waves);
+                const dim3 first_grid = stays ? dim3((f.n_paths + per_group - 1) / per_group) : grid;
+                hipLaunchKernelGGL((fast ? k_shade_fast : exact_stays ? k_shade_stays : k_shade), depth == 0 ? first_grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
             }
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
