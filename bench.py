@@ -143,7 +143,7 @@ class Meter:
     def __init__(self):
         self.mesh_ms = self.bin_ms = self.shade_ms = self.gpu_ms = 0.0
         self.launches = self.tests = self.frames = self.shade_launches = self.casts = 0
-        self.path_bounces = self.paths = self.mesh_rays = 0
+        self.path_bounces = self.path_records = self.paths = self.mesh_rays = 0
 
     def add_marks(self, marks, counted):
         """A sampling step: the kernel times its marks gave, and the work a frame executes (counted once)."""
@@ -156,6 +156,7 @@ class Meter:
         self.tests += counted.triangle_tests
         self.casts += counted.sphere_casts
         self.path_bounces += counted.path_bounces
+        self.path_records += counted.path_records
         self.paths += counted.paths
         self.mesh_rays += counted.mesh_rays
         self.frames += 1
@@ -208,12 +209,12 @@ class Meter:
         """The bounce kernel.  With the exact arithmetic it is bound by instruction issue and is priced against the
         VALU peak: algorithmic work = the sphere scans and box tests of the rays it casts (19 flop per ray-sphere
         test, 22 per ray-box test, the reference's formulation, src/raytrace.cu:53-146; the shading arithmetic itself
-        is not counted), with issue_frac beside it.  With the fast arithmetic it is bound by the bytes of path state it
-        moves (throw-away builds: 56 bytes per path not written, -26 %; 2-3 % fewer instructions, nothing) and is priced
-        against HBM: algorithmic bytes = what the data layout makes a (path, bounce) move -- 76 bytes of state read
-        (the first bounce regenerates the camera ray from 4), 16 bytes of colour and, for a path that goes on, a
-        60-byte record written, 32 bytes per ray queued for the triangle stage -- times the (path, bounce) pairs the
-        kernel processed."""
+        is not counted), with issue_frac beside it.  The fast arithmetic is priced against HBM as well, because the
+        path state the kernel moved was what bound it (throw-away builds: 56 bytes per path not written, -26 %; 2-3 %
+        fewer instructions, nothing) until paths that need nothing from the triangle stage stayed in their lanes:
+        algorithmic bytes = what the data layout makes the kernel move -- 76 bytes read per path it fetches (72 at the
+        first bounce), 76 written per path it hands to the triangle stage, 16 of colour per path that ends, 32 per ray
+        queued.  `bound` names the larger of the two fractions."""
         if not self.shade_launches or self.shade_ms <= 0:
             return None
         casts = self.casts - generate_casts_per_frame * self.frames  # camera rays are cast by k_generate
@@ -227,20 +228,25 @@ class Meter:
             "launches_per_step": self.shade_launches / max(self.frames, 1),
             "casts_per_step": casts / max(self.frames, 1),
             "path_bounces_per_step": self.path_bounces / max(self.frames, 1),
+            "path_records_per_step": self.path_records / max(self.frames, 1),
             "kernel_share_of_step": self.shade_ms / max(self.frames, 1) / step_ms if step_ms else None,
             "sampled_steps": self.frames,
         }
         valu = {"achieved": tflops, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_VECTOR_TFLOPS}
-        if fast and self.path_bounces:
-            first_read = 4  # the first bounce reads the accepted draw and computes the camera ray again
-            algorithmic = (152 * self.path_bounces - 136 * self.paths + first_read * self.paths + 32 * self.mesh_rays)
+        if fast and self.path_records:
+            # fetched: 76 per record (72 at the first bounce); handed on: 76 per record after the first; ended: 16 per path
+            algorithmic = 152 * self.path_records - 64 * self.paths + 32 * self.mesh_rays
             gbps = algorithmic / (self.shade_ms * 1e-3) / 1e9
-            out = {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                   "algorithmic_bytes_per_launch": algorithmic / self.shade_launches,
-                   "note": "dominant kernel of the step; bound by the path state it writes to and reads from HBM; "
-                           "achieved = algorithmic bytes (152 per (path, bounce) less what the first and last bounce do not move, "
-                           "32 per queued ray) over the measured kernel time, traffic = HBM bytes per launch by the PMC counters",
-                   "valu": valu}
+            hbm = {"achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                   "algorithmic_bytes_per_launch": algorithmic / self.shade_launches}
+            note = ("dominant kernel of the step, priced against both ceilings: the path state it moves through HBM (152 bytes per "
+                    "path fetched and handed on, 32 per queued ray; traffic = HBM bytes per launch by the PMC counters) and the "
+                    "sphere scans and box tests of its rays against the VALU peak; issue_frac is the share of the issue slots its "
+                    "instructions take")
+            if hbm["frac"] >= valu["frac"]:
+                out = dict(hbm, bound="hbm", valu=valu, note=note)
+            else:
+                out = dict(valu, bound="valu", hbm=hbm, note=note)
         else:
             out = dict(valu, bound="valu",
                        note="dominant kernel of the step; bound by instruction issue (issue_frac), its own arithmetic (hit selection, "

@@ -123,9 +123,12 @@ typedef struct rt_stats {
                                   over launches (profile != 0 only) */
     uint32_t shade_kernel_launches;
     uint32_t reserved;
-    uint64_t path_bounces;     /* (path, bounce) pairs the bounce kernel processed: the paths alive on entry, summed over
-                                  its launches -- the unit its memory traffic scales with (0 for a scene without triangles,
-                                  whose frame is one kernel with the paths in registers) */
+    uint64_t path_bounces;     /* (path, bounce) pairs the bounce kernel processed: the paths alive on entry to a bounce
+                                  (0 for a scene without triangles, whose frame is one kernel with the paths in registers) */
+    uint64_t path_records;     /* of those, the pairs whose path came from memory: every path at its first bounce and every
+                                  path a bounce wrote out for the triangle stage -- the unit the kernel's memory traffic
+                                  scales with.  Equal to path_bounces with the exact arithmetic; with the fast arithmetic a
+                                  path that needs nothing from the triangle stage stays in its lane for the next bounce. */
 } rt_stats;
 
 /* Device-resident scene plus the work buffers of the frames rendered from it.

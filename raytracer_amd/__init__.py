@@ -67,7 +67,7 @@ class Stats(C.Structure):
         ("mesh_kernel_launches", C.c_uint32), ("batches", C.c_uint32),
         ("paths", C.c_uint64), ("mesh_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
         ("sphere_casts", C.c_uint64), ("shade_kernel_ms", C.c_double), ("shade_kernel_launches", C.c_uint32),
-        ("reserved", C.c_uint32), ("path_bounces", C.c_uint64),
+        ("reserved", C.c_uint32), ("path_bounces", C.c_uint64), ("path_records", C.c_uint64),
     ]
 
 

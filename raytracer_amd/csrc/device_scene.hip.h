@@ -237,23 +237,25 @@ struct SceneCache {
 // array, so the whole cache costs one round trip to memory.
 static_assert(kSphereCache + kMatCache + kLightCache + kBoxCache <= kBlock, "one thread per cached entry");
 __device__ __forceinline__ void stage_scene(const DeviceScene& sc, SceneCache& c) {
-    uint32_t i = threadIdx.x;
-    if (i < kSphereCache) {
-        if (i < sc.n_spheres) {
-            c.sphere[i] = sc.sphere[i];
-            c.sphere_mat[i] = sc.sphere_mat[i];
-        }
-    } else if ((i -= kSphereCache) < kMatCache) {
-        if (i < sc.n_materials) {
-            c.mat_color[i] = sc.mat_color[i];
-            c.mat_ior[i] = sc.mat_ior[i];
-        }
-    } else if ((i -= kMatCache) < kLightCache) {
-        if (i < sc.n_lights) c.light[i] = sc.light[i];
-    } else if ((i -= kLightCache) < kBoxCache) {
-        if (i < sc.n_boxes) {
-            c.box_min[i] = sc.box_min[i];
-            c.box_max[i] = sc.box_max[i];
+    for (uint32_t first = 0; first < kBlock; first += blockDim.x) { // (one trip in a workgroup of kBlock threads)
+        uint32_t i = first + threadIdx.x;
+        if (i < kSphereCache) {
+            if (i < sc.n_spheres) {
+                c.sphere[i] = sc.sphere[i];
+                c.sphere_mat[i] = sc.sphere_mat[i];
+            }
+        } else if ((i -= kSphereCache) < kMatCache) {
+            if (i < sc.n_materials) {
+                c.mat_color[i] = sc.mat_color[i];
+                c.mat_ior[i] = sc.mat_ior[i];
+            }
+        } else if ((i -= kMatCache) < kLightCache) {
+            if (i < sc.n_lights) c.light[i] = sc.light[i];
+        } else if ((i -= kLightCache) < kBoxCache) {
+            if (i < sc.n_boxes) {
+                c.box_min[i] = sc.box_min[i];
+                c.box_max[i] = sc.box_max[i];
+            }
         }
     }
     __syncthreads();
@@ -505,7 +507,9 @@ __device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, const SceneCa
 // index, which spreads the returning atomics over 64 addresses (one address
 // serialises at well under 200 atomics per microsecond).
 // Returns the queue position of this lane's ray (0 when want == false).
-__device__ __forceinline__ uint32_t wave_shard() { return (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kShards; }
+// (the wavefront's index in the grid, for workgroups of any size)
+__device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
+__device__ __forceinline__ uint32_t wave_shard() { return wave_index() % kShards; }
 
 __device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, uint32_t shard, bool want, V3 start, V3 ray, uint32_t slot, float cutoff) {
     const unsigned long long mask = __ballot(want);
@@ -573,7 +577,7 @@ __device__ __forceinline__ void finish_bounce(const Work& w, uint32_t counter, u
 // same n.
 __device__ __forceinline__ void add_casts(const Work& w, uint32_t counter, uint32_t n) {
     if (n && __lane_id() == 0) {
-        const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kCastShards;
+        const uint32_t shard = wave_index() % kCastShards;
         atomicAdd(&w.cast_count[((size_t)counter * kCastShards + shard) * kCountStride], n);
     }
 }
@@ -582,7 +586,7 @@ __device__ __forceinline__ void add_casts(const Work& w, uint32_t counter, uint3
 // (path, bounce) pairs.  All lanes pass the same n.
 __device__ __forceinline__ void add_bounces(const Work& w, uint32_t n) {
     if (n && __lane_id() == 0) {
-        const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kCastShards;
+        const uint32_t shard = wave_index() % kCastShards;
         atomicAdd(&w.bounce_count[(size_t)shard * kCountStride], n);
     }
 }

@@ -432,10 +432,11 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
                 table.count[threadIdx.x] = map.my_count;
                 table.before[threadIdx.x] = map.before;
             }
+            static_assert(kShards <= 64, "the first wavefront fills the table");
         }
         const uint32_t stretch = stretch_of(n_in, f.min_waves);
-        const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-        if ((size_t)blockIdx.x * kWavesPerBlock * stretch >= n_in) return; // the whole workgroup
+        const uint32_t wave = wave_index();
+        if ((size_t)blockIdx.x * (blockDim.x >> 6) * stretch >= n_in) return; // the whole workgroup
         const size_t first = (size_t)wave * stretch;
         cursor = (uint32_t)(first < n_in ? first : n_in);
         cursor_end = (uint32_t)(first + stretch < n_in ? first + stretch : n_in);
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
         sum[pixel] = acc;
     }
     if (f.count_casts && n_casts && __lane_id() == 0) {
-        const uint32_t shard = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) % kCastShards;
+        const uint32_t shard = wave_index() % kCastShards;
         atomicAdd(&cast_count[(size_t)shard * kCountStride], n_casts);
     }
 }

@@ -799,7 +799,8 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
     }
     std::vector<uint32_t> counts(stats ? (size_t)n_counters * kShards * kCountStride : 0);
     std::vector<uint32_t> bounce_counts(stats ? (size_t)kCastShards * kCountStride : 0);
-    uint64_t path_bounces = 0;
+    std::vector<uint32_t> live_counts(counts.size());
+    uint64_t path_bounces = 0, path_records = 0;
     std::vector<uint32_t> cast_counts(stats ? (size_t)n_counters * kCastShards * kCountStride : 0);
     uint64_t mesh_rays = 0, paths = 0, sphere_casts = 0;
     uint32_t batches = 0;
@@ -847,9 +848,13 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
                 // (RT_AMD_EXACT_STAYS: that control flow with the exact arithmetic, for the tests against the oracle.)
                 static const bool exact_stays = std::getenv("RT_AMD_EXACT_STAYS") != nullptr;
                 const bool stays = fast || exact_stays;
-                const uint32_t per_group = kWavesPerBlock * stretch_of(f.n_paths, f.min_waves);
+#ifndef RT_STAYS_BLOCK
+#define RT_STAYS_BLOCK kBlock
+#endif
+                const uint32_t waves_per_group = stays ? RT_STAYS_BLOCK / 64 : kWavesPerBlock;
+                const uint32_t per_group = waves_per_group * stretch_of(f.n_paths, f.min_waves);
                 const dim3 first_grid = stays ? dim3((f.n_paths + per_group - 1) / per_group) : grid;
-                hipLaunchKernelGGL((fast ? k_shade_fast : exact_stays ? k_shade_stays : k_shade), depth == 0 ? first_grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
+                hipLaunchKernelGGL((fast ? k_shade_fast : exact_stays ? k_shade_stays : k_shade), depth == 0 ? first_grid : dim3((grid.x + kShards) * (kWavesPerBlock / waves_per_group)), stays ? dim3(RT_STAYS_BLOCK) : block, 0, stream, s->d, w, f, depth);
             }
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
@@ -866,6 +871,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         }
         if (stats) { // the counters are reused by the next batch: read them now
             HIP_TRY(hipMemcpyAsync(counts.data(), w.q_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(live_counts.data(), w.live_count, live_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(bounce_counts.data(), w.bounce_count, bounce_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(cast_counts.data(), w.cast_count, cast_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -875,6 +881,10 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             for (size_t i = 0; i < cast_counts.size(); i += kCountStride) sphere_casts += cast_counts[i];
             mesh_rays += batch_rays;
             for (size_t i = 0; i < bounce_counts.size(); i += kCountStride) path_bounces += bounce_counts[i];
+            // the first launch fetches every path of the batch, launch d > 0 the paths on its list
+            if (opt->max_depth > 0) path_records += f.n_paths;
+            for (int d = 1; d < opt->max_depth; d++)
+                for (uint32_t shard = 0; shard < kShards; shard++) path_records += live_counts[((size_t)d * kShards + shard) * kCountStride];
             if (cull) {
                 for (size_t i = 0; i < cl_words; i += kCountStride) tests += (uint64_t)cl_counts[i] * s->cluster_tris[(i / kCountStride) % s->d.n_clusters];
             } else {
@@ -893,6 +903,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         stats->paths = paths;
         stats->mesh_rays = mesh_rays;
         stats->path_bounces = path_bounces;
+        stats->path_records = path_records;
         stats->triangle_tests = tests;
         stats->sphere_casts = sphere_casts;
     }

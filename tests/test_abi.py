@@ -46,7 +46,7 @@ def test_struct_sizes_match_the_header():
     # computed from the field lists in rt_amd.h with natural alignment on LP64
     assert C.sizeof(rt.Camera) == 9 * 4 + 3 * 4 + 4 * 4 + 3 * 4
     assert C.sizeof(rt.Options) == 8 * 4
-    assert C.sizeof(rt.Stats) == 3 * 8 + 2 * 4 + 4 * 8 + 8 + 2 * 4 + 8
+    assert C.sizeof(rt.Stats) == 3 * 8 + 2 * 4 + 4 * 8 + 8 + 2 * 4 + 2 * 8
     assert C.sizeof(rt.SceneDesc) == 6 * 8 + 16 * 8  # six counts (padded to 8) and sixteen pointers
 
 

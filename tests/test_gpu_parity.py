@@ -308,3 +308,10 @@ def test_counted_triangle_tests_and_footprint_of_a_scene_handle():
     # a frame of one bounce: exactly one pair per path
     _, st1 = dev.render(cam, rt.make_options(seed=1, max_depth=1))
     assert st1.path_bounces == st1.paths
+    # the exact arithmetic fetches a path for every bounce; the fast one keeps a path in its lane while it needs nothing
+    # from the triangle stage (most bounces of this frame: the room is large, the cat small), and counts the same bounces
+    assert st.path_records == st.path_bounces
+    _, stf = dev.render(cam, rt.make_options(seed=1, arithmetic=1))
+    assert stf.path_bounces / stf.paths == pytest.approx(2.94, abs=0.2)
+    assert stf.paths < stf.path_records < 0.7 * stf.path_bounces
+    print(f"fast arithmetic: {stf.path_records / stf.paths:.2f} fetches for {stf.path_bounces / stf.paths:.2f} bounces per path")
