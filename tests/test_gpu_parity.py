@@ -4,6 +4,7 @@ Both sides draw from the same counter-based generator and use the same fixed
 polynomial kernels for log/sin/cos/pow, and both are compiled without
 floating-point contraction, so the comparison is BIT-EXACT in every mode.
 """
+import os
 import numpy as np
 import pytest
 
@@ -310,7 +311,8 @@ def test_counted_triangle_tests_and_footprint_of_a_scene_handle():
     assert st1.path_bounces == st1.paths
     # the exact arithmetic fetches a path for every bounce; the fast one keeps a path in its lane while it needs nothing
     # from the triangle stage (most bounces of this frame: the room is large, the cat small), and counts the same bounces
-    assert st.path_records == st.path_bounces
+    if "RT_AMD_EXACT_STAYS" not in os.environ:  # (the validation knob runs the exact arithmetic through the fast kernel's control flow)
+        assert st.path_records == st.path_bounces
     _, stf = dev.render(cam, rt.make_options(seed=1, arithmetic=1))
     assert stf.path_bounces / stf.paths == pytest.approx(2.94, abs=0.2)
     assert stf.paths < stf.path_records < 0.7 * stf.path_bounces
