@@ -250,8 +250,13 @@ __host__ __device__ inline uint32_t stretch_of(uint32_t n_in, uint32_t min_waves
     const uint32_t want = n_in / (64u * min_waves);
     return 64u * (want < 1u ? 1u : want > kMaxStretch / 64u ? kMaxStretch / 64u : want);
 }
-// (Measured on the 8.4 M paths of the headline frame, stretches of 256 / 512 / 1 024: 4 690 / 4 795 / 4 733 Mpaths/s.)
-constexpr uint32_t kMinStretchWaves = 16384; // 16 wavefronts per SIMD
+// (Measured on the 8.4 M paths of the headline frame, stretches of 256 / 512 / 1 024: 4 690 / 4 795 / 4 733 Mpaths/s;
+// on 4.2 M and 2.1 M paths 512 is the best as well, so the lists of a million entries and more get the longest
+// stretches and only shorter ones are spread thinner.)
+constexpr uint32_t kMinStretchWaves = 2048; // 2 wavefronts per SIMD
+// Batches below this many paths take the kernel with a launch per bounce (measured with three frames in flight, 1.05 M /
+// 2.1 M paths: 0.31 / 0.53 ms per frame that way, 0.33 / 0.51 ms with paths that stay in their lanes).
+constexpr uint32_t kStaysFromPaths = 1536u * 1024u;
 
 // One ray per lane against triangle pairs [first, last): two pairs per trip,
 // two SGPR sets.  Scalar loads return out of order, so the only wait available

@@ -679,9 +679,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     shade_bounce<ExactMath>(sc, w, f, depth);
 }
 
-// rt_options.arithmetic = 1
+// rt_options.arithmetic = 1: batches of kStaysFromPaths paths or more ...
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast(DeviceScene sc, Work w, Frame f, int depth) {
     shade_bounce<FastMath, true>(sc, w, f, depth);
+}
+
+// ... and smaller ones, which have too few wavefronts for long stretches and are not bound by memory: a launch per bounce,
+// every path of a list in a lane of its own.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast_each(DeviceScene sc, Work w, Frame f, int depth) {
+    shade_bounce<FastMath>(sc, w, f, depth);
 }
 
 // The control flow of k_shade_fast with the arithmetic of k_shade: what the tests hold against the oracle bit for bit

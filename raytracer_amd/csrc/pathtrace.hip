@@ -847,14 +847,11 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
                 // of the later launches hold is not known here.
                 // (RT_AMD_EXACT_STAYS: that control flow with the exact arithmetic, for the tests against the oracle.)
                 static const bool exact_stays = std::getenv("RT_AMD_EXACT_STAYS") != nullptr;
-                const bool stays = fast || exact_stays;
-#ifndef RT_STAYS_BLOCK
-#define RT_STAYS_BLOCK kBlock
-#endif
-                const uint32_t waves_per_group = stays ? RT_STAYS_BLOCK / 64 : kWavesPerBlock;
-                const uint32_t per_group = waves_per_group * stretch_of(f.n_paths, f.min_waves);
+                const bool stays = (fast && f.n_paths >= kStaysFromPaths) || exact_stays;
+                const uint32_t per_group = kWavesPerBlock * stretch_of(f.n_paths, f.min_waves);
                 const dim3 first_grid = stays ? dim3((f.n_paths + per_group - 1) / per_group) : grid;
-                hipLaunchKernelGGL((fast ? k_shade_fast : exact_stays ? k_shade_stays : k_shade), depth == 0 ? first_grid : dim3((grid.x + kShards) * (kWavesPerBlock / waves_per_group)), stays ? dim3(RT_STAYS_BLOCK) : block, 0, stream, s->d, w, f, depth);
+                hipLaunchKernelGGL((exact_stays && !fast ? k_shade_stays : !fast ? k_shade : stays ? k_shade_fast : k_shade_fast_each),
+                                   depth == 0 ? first_grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
             }
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
