@@ -214,7 +214,7 @@ class Meter:
         fewer instructions, nothing) until paths that need nothing from the triangle stage stayed in their lanes:
         algorithmic bytes = what the data layout makes the kernel move -- 76 bytes read per path it fetches (72 at the
         first bounce), 76 written per path it hands to the triangle stage, 16 of colour per path that ends, 32 per ray
-        queued.  `bound` names the larger of the two fractions."""
+        queued.  `bound` names the nearer ceiling by the counters (hbm_frac against issue_frac)."""
         if not self.shade_launches or self.shade_ms <= 0:
             return None
         casts = self.casts - generate_casts_per_frame * self.frames  # camera rays are cast by k_generate
@@ -243,7 +243,8 @@ class Meter:
                     "path fetched and handed on, 32 per queued ray; traffic = HBM bytes per launch by the PMC counters) and the "
                     "sphere scans and box tests of its rays against the VALU peak; issue_frac is the share of the issue slots its "
                     "instructions take")
-            if hbm["frac"] >= valu["frac"]:
+            # the nearer ceiling by the counters: HBM bytes moved over the HBM peak, or issue slots taken
+            if max(counters.get("hbm_frac") or 0.0, hbm["frac"]) >= (counters.get("issue_frac") or 0.0):
                 out = dict(hbm, bound="hbm", valu=valu, note=note)
             else:
                 out = dict(valu, bound="valu", hbm=hbm, note=note)

@@ -31,6 +31,7 @@ constexpr uint32_t kFusedGroup = 16;        // clusters per group at most where 
 constexpr uint32_t kFusedMaxGroups = 64;    // ... which is for meshes of up to 64 such groups
 constexpr size_t kClusterListBudget = size_t(24) << 30; // most bytes the per-cluster ray lists may take (of 288 GB)
 
+constexpr uint32_t kGenWalks = 0x80000000u;    // in Work::gen: the camera ray is queued for the first triangle stage
 constexpr uint32_t kLivePending = 0x80000000u; // in an entry of the live-path list: the path has F_PENDING set
 
 constexpr uint32_t F_ALIVE = 1u;   // the path still bounces
@@ -106,6 +107,9 @@ struct Work {
     // two buffers (bounce d reads buffer d & 1 and fills the other)
     uint32_t* live;
     uint32_t* live_count;    // kShards counters per bounce
+    // Per path, when the first bounce regenerates the camera rays (k_generate's `regenerate`) instead of reading them back:
+    // first random dimension of the accepted anti-aliasing draw, kGenWalks set when the camera ray walks the mesh
+    uint32_t* gen;
     uint32_t live_capacity;  // path indices reserved per shard
     uint32_t live_total;     // = kShards * live_capacity: entries of one buffer
 };

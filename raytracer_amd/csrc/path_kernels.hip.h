@@ -168,7 +168,10 @@ __device__ __forceinline__ float nearest_sphere_from_eye(const DeviceScene& sc, 
 }
 
 template <uint32_t kPaths, class M>
-__global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f) {
+// regenerate: leave (accepted draw, walks the mesh) per path instead of the ray; the first bounce then computes the
+// camera ray again (k_shade_fast_first).  (An argument of its own: one more word in Frame costs the bounce kernels,
+// which are at the limit of their scalar registers, two dozen spills.)
+__global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f, int regenerate) {
     __shared__ SceneCache cache;
     __shared__ uint32_t key_kp[kPaths][kBlock], key_ks[kPaths][kBlock];
     __shared__ uint32_t accepted[kPaths][kBlock]; // first dimension of the accepted draw
@@ -215,14 +218,14 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
         const bool alive = p < f.n_paths;
         V3 start = mk(f.pos[0], f.pos[1], f.pos[2]);
         V3 ray = mk(0.f, 0.f, 1.f);
-        uint32_t dim = 0;
+        uint32_t first_dim = 0, dim = 0;
         if (alive) {
             const uint32_t pixel = path_pixel(f, p);
             const uint32_t ux = pixel % f.width, uy = pixel / f.width;
             rt_rng_key key;
             key.kp = key_kp[r][threadIdx.x];
             key.ks = key_ks[r][threadIdx.x];
-            dim = f.antialiasing ? accepted[r][threadIdx.x] : 0u;
+            first_dim = dim = f.antialiasing ? accepted[r][threadIdx.x] : 0u;
             ray = camera_ray<M>(f, key, ux, uy, dim);
         }
         int sid = -1;
@@ -232,11 +235,19 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             ts = nearest_sphere_from_eye<M>(sc, cache, eye_oc, start, ray, sid);
             walk = needs_mesh<true, M>(sc, cache, f.bounding_box, ray, start);
         }
-        if (alive) {
-            w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
-            w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
+        if (regenerate) { // the first bounce computes the ray again: it needs the accepted draw and, if the ray walks the mesh, a hit slot
+            if (alive) {
+                w.gen[p] = first_dim | (walk ? kGenWalks : 0u);
+                if (walk) w.hit[p] = kNoHit;
+            }
+            enqueue(w, 0, wave_shard(), alive && walk, start, ray, p, ts);
+        } else {
+            if (alive) {
+                w.thr[p] = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
+                w.rad[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
+            }
+            commit_ray(w, 0, alive, p, start, ray, ts, sid, walk);
         }
-        commit_ray(w, 0, alive, p, start, ray, ts, sid, walk);
         n_casts += (uint32_t)__popcll(__ballot(alive));
     }
     if (f.count_casts) add_casts(w, 0, n_casts);
@@ -399,9 +410,13 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
 // are at different bounces (each one's index rides in its flags, above kBounceShift), all of them at `depth` or
 // beyond, so max_depth launches still see every path to its end.  A path is written at most once per kernel, always
 // to the list and queue of stage depth + 1, and a wavefront writes at most the paths of its own stretch there.
-template <class M, bool kContinue = false>
+// kRegenerate (first bounce of a launch per bounce, k_generate's `regenerate`): the camera ray is computed again from what
+// k_generate left in Work::gen instead of being read back.
+template <class M, bool kContinue = false, bool kRegenerate = false>
 __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& w, const Frame& f, int depth) {
+    static_assert(!(kContinue && kRegenerate), "lanes that fetch a few paths at a time would compute their rays with a few lanes");
     __shared__ SceneCache cache;
+    __shared__ float4 eye_oc[kRegenerate ? kSphereCache : 1];
     // The first bounce sees every path; later ones walk the list of paths the previous bounce
     // left alive, so that the lanes of a wavefront are all busy however many paths have ended.
     // A list entry is the path index, with kLivePending set when light terms of the previous
@@ -443,6 +458,10 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         p = 0xffffffffu;
     }
     stage_scene(sc, cache);
+    if constexpr (kRegenerate) {
+        stage_eye<M>(sc, cache, f, eye_oc);
+        __syncthreads();
+    }
     // the path's state on entry: colour and flags, ray (origin + nearest-sphere distance, direction + sphere index),
     // weight + next random dimension, the triangle stage's answer; read from memory or kept from the previous trip of
     // the loop below (kContinue)
@@ -482,7 +501,21 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         fresh = take && p < f.n_paths;
     }
     if (fresh) {
-        {
+        if constexpr (kRegenerate) {
+            const uint32_t g = w.gen[p];
+            if (g & kGenWalks) key = w.hit[p];
+            const uint32_t pixel = path_pixel(f, p);
+            const uint32_t ux = pixel % f.width, uy = pixel / f.width;
+            uint32_t dim = g & ~kGenWalks;
+            const V3 eye = mk(f.pos[0], f.pos[1], f.pos[2]);
+            const V3 cray = camera_ray<M>(f, rt_rng_make_key(f.seed, pixel, path_sample(f, p)), ux, uy, dim);
+            int csid;
+            const float cts = nearest_sphere_from_eye<M>(sc, cache, eye_oc, eye, cray, csid);
+            rad = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
+            th = make_float4(1.f, 1.f, 1.f, __uint_as_float(dim));
+            ro4 = make_float4(eye.x, eye.y, eye.z, cts);
+            rd4 = make_float4(cray.x, cray.y, cray.z, __int_as_float(csid));
+        } else {
             // the whole state of the path in one round trip to memory
             rad = w.rad[p];
             ro4 = w.ray_o[at_index], rd4 = w.ray_d[at_index], th = w.thr[at_index];
@@ -688,6 +721,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
 // every path of a list in a lane of its own.
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast_each(DeviceScene sc, Work w, Frame f, int depth) {
     shade_bounce<FastMath>(sc, w, f, depth);
+}
+
+// ... whose first bounce computes the camera ray again instead of reading it back (k_generate's `regenerate`)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast_first(DeviceScene sc, Work w, Frame f) {
+    shade_bounce<FastMath, false, true>(sc, w, f, 0);
 }
 
 // The control flow of k_shade_fast with the arithmetic of k_shade: what the tests hold against the oracle bit for bit

@@ -230,6 +230,7 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     w.ray_d.base = rays + 1;
     w.thr = c.take<float4>(2 * live_total);
     w.rad = c.take<float4>(n_paths);
+    w.gen = c.take<uint32_t>(n_paths);
     w.pend = c.take<float4>((size_t)n_paths * nl);
     w.hit = c.take<unsigned long long>(2 * live_total + (size_t)n_paths * nl);
     w.q_o = c.take<float4>(2 * queue_entries);
@@ -298,7 +299,6 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     f.max_depth = opt->max_depth;
     f.count_casts = 0;
     f.prune_zero_terms = 0;
-    // (a frame without bounces has no first bounce to compute the camera rays again)
     // (validation knob: short stretches are what small frames get; RT_AMD_STRETCH_WAVES=1 gives them long ones)
     static const int stretch_waves = [] { const char* e = std::getenv("RT_AMD_STRETCH_WAVES"); return e ? std::atoi(e) : 0; }();
     f.min_waves = stretch_waves > 0 ? (uint32_t)stretch_waves : kMinStretchWaves;
@@ -832,22 +832,29 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         }
         // paths per lane: as many as still leave 2 048 workgroups (8 per CU)
         const bool fast = opt->arithmetic != 0;
+        // The bounce kernel of the fast arithmetic.  Large batches of frames with indirect light and object boxes: paths stay
+        // in their lanes while they need nothing from the triangle stage (k_shade_fast).  Otherwise a launch per bounce, the first
+        // of which computes the camera rays again instead of reading them back (a frame without bounces has none).
+        // (RT_AMD_EXACT_STAYS: the control flow of the former with the exact arithmetic, for the tests against the oracle.)
+        static const bool exact_stays = std::getenv("RT_AMD_EXACT_STAYS") != nullptr;
+        // (without the object boxes every ray of a scene with triangles walks the mesh: no path could stay)
+        const bool stays = (fast && opt->indirect != 0 && opt->bounding_box != 0 && f.n_paths >= kStaysFromPaths) || exact_stays;
+        const int regenerate = fast && !stays && opt->max_depth >= 1;
         if (f.n_paths >= 2048u * kBlock * 4)
-            hipLaunchKernelGGL((fast ? k_generate<4, FastMath> : k_generate<4, ExactMath>), dim3((f.n_paths + kBlock * 4 - 1) / (kBlock * 4)), block, 0, stream, s->d, w, f);
+            hipLaunchKernelGGL((fast ? k_generate<4, FastMath> : k_generate<4, ExactMath>), dim3((f.n_paths + kBlock * 4 - 1) / (kBlock * 4)), block, 0, stream, s->d, w, f, regenerate);
         else if (f.n_paths >= 2048u * kBlock * 2)
-            hipLaunchKernelGGL((fast ? k_generate<2, FastMath> : k_generate<2, ExactMath>), dim3((f.n_paths + kBlock * 2 - 1) / (kBlock * 2)), block, 0, stream, s->d, w, f);
+            hipLaunchKernelGGL((fast ? k_generate<2, FastMath> : k_generate<2, ExactMath>), dim3((f.n_paths + kBlock * 2 - 1) / (kBlock * 2)), block, 0, stream, s->d, w, f, regenerate);
         else
-            hipLaunchKernelGGL((fast ? k_generate<1, FastMath> : k_generate<1, ExactMath>), grid, block, 0, stream, s->d, w, f);
+            hipLaunchKernelGGL((fast ? k_generate<1, FastMath> : k_generate<1, ExactMath>), grid, block, 0, stream, s->d, w, f, regenerate);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
             if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
-            {
-                // The kernels whose paths stay in their lanes: a wavefront takes stretch_of() paths; how many the lists
-                // of the later launches hold is not known here.
-                // (RT_AMD_EXACT_STAYS: that control flow with the exact arithmetic, for the tests against the oracle.)
-                static const bool exact_stays = std::getenv("RT_AMD_EXACT_STAYS") != nullptr;
-                const bool stays = (fast && f.n_paths >= kStaysFromPaths) || exact_stays;
+            if (depth == 0 && regenerate) {
+                hipLaunchKernelGGL(k_shade_fast_first, grid, block, 0, stream, s->d, w, f);
+            } else {
+                // (a wavefront of the kernels whose paths stay in their lanes takes stretch_of() paths; how many the lists
+                // of the later launches hold is not known here)
                 const uint32_t per_group = kWavesPerBlock * stretch_of(f.n_paths, f.min_waves);
                 const dim3 first_grid = stays ? dim3((f.n_paths + per_group - 1) / per_group) : grid;
                 hipLaunchKernelGGL((exact_stays && !fast ? k_shade_stays : !fast ? k_shade : stays ? k_shade_fast : k_shade_fast_each),
