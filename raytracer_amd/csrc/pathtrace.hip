@@ -188,6 +188,13 @@ struct Carver {
 // Lays the work buffers for batches of up to n_paths paths and n_counters triangle stages out in
 // `arena` (null: only ws->bytes and the capacities are computed).  The cluster lists get at most
 // list_budget bytes; a triangle stage is cut into tiles of rays when that does not cover the queue.
+// Fewest wavefronts a long input of a kernel whose paths stay in their lanes is spread over (stretch_of).
+// (Validation knob: small frames get short stretches; RT_AMD_STRETCH_WAVES=1 gives them the longest.)
+uint32_t stretch_min_waves() {
+    static const int forced = [] { const char* e = std::getenv("RT_AMD_STRETCH_WAVES"); return e ? std::atoi(e) : 0; }();
+    return forced > 0 ? (uint32_t)forced : kMinStretchWaves;
+}
+
 int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, size_t list_budget, unsigned char* arena, WorkSet* ws) {
     const size_t nl = d.n_lights ? d.n_lights : 1;
     // a shard receives the rays of every kShards-th wavefront of a path kernel
@@ -195,8 +202,10 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     // up to kShards workgroups more than the paths need)
     // (or of every kShards-th workgroup of the kernels that reserve by workgroup: what is reserved here covers both)
     const size_t n_groups_of_paths = ((size_t)n_paths + kBlock - 1) / kBlock + kShards;
-    // (a wavefront of those kernels takes up to kMaxStretch paths; with w wavefronts launched a shard serves ceil(w / kShards))
-    const size_t per_shard = ((n_groups_of_paths + kShards - 1) / kShards) * kBlock + 2 * kMaxStretch;
+    // (a wavefront of the kernels whose paths stay in their lanes writes up to a stretch of S entries of its input, and
+    // of w = ceil(n / S) wavefronts a shard serves ceil(w / kShards): less than n / kShards + 2 S entries; S grows with n)
+    const size_t longest_stretch = stretch_of((uint32_t)std::min<size_t>(n_groups_of_paths * kBlock, 0xffffffffu), stretch_min_waves());
+    const size_t per_shard = ((n_groups_of_paths + kShards - 1) / kShards) * kBlock + 2 * longest_stretch;
     // k_shade: a wavefront queues at most 64 * (1 + lights) rays; k_generate: 64 * kGenPaths, from fewer wavefronts
     size_t shard_capacity = per_shard * (1 + nl);
     for (size_t r = 2; r <= kGenPaths; r *= 2) {
@@ -299,9 +308,7 @@ Frame make_frame(const rt_camera* cam, const rt_options* opt) {
     f.max_depth = opt->max_depth;
     f.count_casts = 0;
     f.prune_zero_terms = 0;
-    // (validation knob: short stretches are what small frames get; RT_AMD_STRETCH_WAVES=1 gives them long ones)
-    static const int stretch_waves = [] { const char* e = std::getenv("RT_AMD_STRETCH_WAVES"); return e ? std::atoi(e) : 0; }();
-    f.min_waves = stretch_waves > 0 ? (uint32_t)stretch_waves : kMinStretchWaves;
+    f.min_waves = stretch_min_waves();
     return f;
 }
 
