@@ -254,6 +254,8 @@ __host__ __device__ inline uint32_t stretch_of(uint32_t n_in, uint32_t min_waves
 // on 4.2 M and 2.1 M paths 512 is the best as well, so the lists of a million entries and more get the longest
 // stretches and only shorter ones are spread thinner.)
 constexpr uint32_t kMinStretchWaves = 2048; // 2 wavefronts per SIMD
+// (Measured, 0 / 16 / 24 / 32 / 48 / 64: 5 130 / 5 185 / 5 193 / 5 205 / 5 205 / 5 206 Mpaths/s on the headline frame.)
+constexpr uint32_t kKeepLanes = 32; // fewest paths a wavefront whose stretch is used up goes on with
 // Batches below this many paths take the kernel with a launch per bounce (measured with three frames in flight, 1.05 M /
 // 2.1 M paths: 0.31 / 0.53 ms per frame that way, 0.33 / 0.51 ms with paths that stay in their lanes).
 constexpr uint32_t kStaysFromPaths = 1536u * 1024u;

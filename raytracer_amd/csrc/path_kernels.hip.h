@@ -683,6 +683,11 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         walk = needs_mesh<false, M>(sc, cache, f.bounding_box, ray, start);
     }
     at_once = kContinue && alive && !walk && !deferred;
+    if constexpr (kContinue) {
+        // The stretch is used up and few paths are left in the wavefront: they go to the next launch's list like the
+        // others (a trip costs a wavefront the same with 10 lanes as with 64; there they fill lanes again).
+        if (cursor == cursor_end && (uint32_t)__popcll(__ballot(at_once)) < kKeepLanes) at_once = false;
+    }
     if (open && !at_once) {
         if (!alive) flags &= ~F_ALIVE;
         w.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float(flags));
