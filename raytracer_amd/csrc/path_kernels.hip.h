@@ -20,17 +20,33 @@ struct Frame {
     int32_t indirect, antialiasing, bounding_box, max_depth;
     int32_t count_casts;    // count the rays tested against the spheres (statistics)
     uint32_t min_waves;     // kernels whose paths stay in their lanes: the fewest wavefronts a long input is spread over (stretch_of)
-                            // bounce computes the camera ray again: 136 bytes of state per path that make no round trip
-                            // through memory, for some 150 instructions more in a kernel that is short of bandwidth,
-                            // not of issue slots (fast arithmetic only: there the two kernels compute the same bits
-                            // with a few dozen instructions; the exact arithmetic would pay a few hundred)
     int32_t prune_zero_terms; // work whose result can only add exact zeros is dropped: the mesh walk of a shadow
                               // ray with a zero contribution, the rest of a path whose weight is zero (not in
                               // the exhaustive mode, which keeps the reference's amount of work)
 };
 
-__device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return f.pixel_offset + p % f.n_pixels; }
-__device__ __forceinline__ uint32_t path_sample(const Frame& f, uint32_t p) { return f.sample_begin + p / f.n_pixels; }
+// Path p of a batch is sample p / n_pixels of pixel p % n_pixels.  A batch holds at most 2^24 paths, so p and n_pixels
+// are exact floats: the quotient by a reciprocal is off by at most one (error below 3 / n_pixels of a quotient below
+// 2^24 / n_pixels; n_pixels of 1 and 2 have exact reciprocals), which the remainder shows and one step either way
+// repairs -- a dozen instructions where an integer division and a remainder by an unknown divisor take forty.
+struct PathId {
+    uint32_t pixel, sample;
+};
+__device__ __forceinline__ PathId path_id(const Frame& f, uint32_t p) {
+    static_assert(kMaxPathsPerBatch <= (1u << 24), "path indices must be exact in single precision");
+    const float inv = __builtin_amdgcn_rcpf((float)f.n_pixels);
+    uint32_t q = (uint32_t)((float)p * inv);
+    int32_t r = (int32_t)(p - q * f.n_pixels);
+    if (r < 0) {
+        q -= 1u;
+        r += (int32_t)f.n_pixels;
+    } else if (r >= (int32_t)f.n_pixels) {
+        q += 1u;
+        r -= (int32_t)f.n_pixels;
+    }
+    return {f.pixel_offset + (uint32_t)r, f.sample_begin + q};
+}
+__device__ __forceinline__ uint32_t path_pixel(const Frame& f, uint32_t p) { return path_id(f, p).pixel; }
 
 // State write-back of a freshly generated ray whose nearest sphere (ts, sid)
 // and mesh verdict are known, and queueing for k_mesh.  All lanes of the
@@ -186,7 +202,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
     for (uint32_t r = 0; r < kPaths; r++) {
         const uint32_t p = base + r * kBlock;
         if (p < f.n_paths) {
-            const rt_rng_key key = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
+            const PathId id = path_id(f, p);
+            const rt_rng_key key = rt_rng_make_key(f.seed, id.pixel, id.sample);
             key_kp[r][threadIdx.x] = key.kp;
             key_ks[r][threadIdx.x] = key.ks;
             accepted[r][threadIdx.x] = 0;
@@ -504,11 +521,12 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         if constexpr (kRegenerate) {
             const uint32_t g = w.gen[p];
             if (g & kGenWalks) key = w.hit[p];
-            const uint32_t pixel = path_pixel(f, p);
+            const PathId id = path_id(f, p);
+            const uint32_t pixel = id.pixel;
             const uint32_t ux = pixel % f.width, uy = pixel / f.width;
             uint32_t dim = g & ~kGenWalks;
             const V3 eye = mk(f.pos[0], f.pos[1], f.pos[2]);
-            const V3 cray = camera_ray<M>(f, rt_rng_make_key(f.seed, pixel, path_sample(f, p)), ux, uy, dim);
+            const V3 cray = camera_ray<M>(f, rt_rng_make_key(f.seed, pixel, id.sample), ux, uy, dim);
             int csid;
             const float cts = nearest_sphere_from_eye<M>(sc, cache, eye_oc, eye, cray, csid);
             rad = make_float4(0.f, 0.f, 0.f, __uint_as_float(F_ALIVE));
@@ -583,7 +601,8 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
                 }
                 weight = xyz(th);
                 uint32_t dim = __float_as_uint(th.w);
-                const rt_rng_key rng = rt_rng_make_key(f.seed, path_pixel(f, p), path_sample(f, p));
+                const PathId id = path_id(f, p);
+                const rt_rng_key rng = rt_rng_make_key(f.seed, id.pixel, id.sample);
                 respond_to_hit<M>(sc, cache, f, rng, bounce, m, P, N, start, ray, weight, colour, dim, flags, alive, lit, tinted);
                 next_dim = dim;
             }
