@@ -228,7 +228,11 @@ __device__ __forceinline__ V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
 // read from global memory.
 constexpr uint32_t kSphereCache = 64, kMatCache = 128, kLightCache = 8, kBoxCache = 8;
 
-struct SceneCache {
+// kFits: the scene's tables are known to fit (the host checked the counts): no entry is ever fetched from global memory,
+// and the kernels carry neither the code nor the pointers for it.
+template <bool kFitsScene>
+struct SceneCacheT {
+    static constexpr bool kFits = kFitsScene;
     float4 sphere[kSphereCache];
     float4 mat_color[kMatCache];
     float2 mat_ior[kMatCache];
@@ -236,11 +240,13 @@ struct SceneCache {
     float4 light[kLightCache];
     float4 box_min[kBoxCache], box_max[kBoxCache];
 };
+using SceneCache = SceneCacheT<false>;
 
 // All threads of the workgroup must call it.  Every thread copies at most one entry of one
 // array, so the whole cache costs one round trip to memory.
 static_assert(kSphereCache + kMatCache + kLightCache + kBoxCache <= kBlock, "one thread per cached entry");
-__device__ __forceinline__ void stage_scene(const DeviceScene& sc, SceneCache& c) {
+template <class Cache>
+__device__ __forceinline__ void stage_scene(const DeviceScene& sc, Cache& c) {
     for (uint32_t first = 0; first < kBlock; first += blockDim.x) { // (one trip in a workgroup of kBlock threads)
         uint32_t i = first + threadIdx.x;
         if (i < kSphereCache) {
@@ -267,46 +273,53 @@ __device__ __forceinline__ void stage_scene(const DeviceScene& sc, SceneCache& c
 
 // Single entries: the LDS read is unconditional (index wrapped into the cache) and the rare entry
 // beyond the cache replaces it, so that the common case is a plain LDS read.
-__device__ __forceinline__ float4 sphere_at(const DeviceScene& sc, const SceneCache& c, uint32_t i) {
+template <class Cache>
+__device__ __forceinline__ float4 sphere_at(const DeviceScene& sc, const Cache& c, uint32_t i) {
     float4 v = c.sphere[i % kSphereCache];
-    if (i >= kSphereCache) v = sc.sphere[i];
+    if (!Cache::kFits && i >= kSphereCache) v = sc.sphere[i];
     return v;
 }
-__device__ __forceinline__ int sphere_material(const DeviceScene& sc, const SceneCache& c, uint32_t i) {
+template <class Cache>
+__device__ __forceinline__ int sphere_material(const DeviceScene& sc, const Cache& c, uint32_t i) {
     int v = c.sphere_mat[i % kSphereCache];
-    if (i >= kSphereCache) v = sc.sphere_mat[i];
+    if (!Cache::kFits && i >= kSphereCache) v = sc.sphere_mat[i];
     return v;
 }
-__device__ __forceinline__ float4 material_color(const DeviceScene& sc, const SceneCache& c, uint32_t m) {
+template <class Cache>
+__device__ __forceinline__ float4 material_color(const DeviceScene& sc, const Cache& c, uint32_t m) {
     float4 v = c.mat_color[m % kMatCache];
-    if (m >= kMatCache) v = sc.mat_color[m];
+    if (!Cache::kFits && m >= kMatCache) v = sc.mat_color[m];
     return v;
 }
-__device__ __forceinline__ float2 material_ior(const DeviceScene& sc, const SceneCache& c, uint32_t m) {
+template <class Cache>
+__device__ __forceinline__ float2 material_ior(const DeviceScene& sc, const Cache& c, uint32_t m) {
     float2 v = c.mat_ior[m % kMatCache];
-    if (m >= kMatCache) v = sc.mat_ior[m];
+    if (!Cache::kFits && m >= kMatCache) v = sc.mat_ior[m];
     return v;
 }
-__device__ __forceinline__ float4 light_at(const DeviceScene& sc, const SceneCache& c, uint32_t l) {
+template <class Cache>
+__device__ __forceinline__ float4 light_at(const DeviceScene& sc, const Cache& c, uint32_t l) {
     float4 v = c.light[l % kLightCache];
-    if (l >= kLightCache) v = sc.light[l];
+    if (!Cache::kFits && l >= kLightCache) v = sc.light[l];
     return v;
 }
 
 // body(i, sphere i) for every sphere in index order: the cached ones from LDS, the rest from global memory.
-template <typename Body>
-__device__ __forceinline__ void for_each_sphere(const DeviceScene& sc, const SceneCache& c, Body&& body) {
+template <typename Body, class Cache>
+__device__ __forceinline__ void for_each_sphere(const DeviceScene& sc, const Cache& c, Body&& body) {
     const uint32_t cached = min(sc.n_spheres, kSphereCache);
     for (uint32_t i = 0; i < cached; i++) body(i, c.sphere[i]);
-    for (uint32_t i = cached; i < sc.n_spheres; i++) body(i, sc.sphere[i]);
+    if constexpr (!Cache::kFits)
+        for (uint32_t i = cached; i < sc.n_spheres; i++) body(i, sc.sphere[i]);
 }
 
 // body(box_min o, box_max o) for every object box in index order.
-template <typename Body>
-__device__ __forceinline__ void for_each_box(const DeviceScene& sc, const SceneCache& c, Body&& body) {
+template <typename Body, class Cache>
+__device__ __forceinline__ void for_each_box(const DeviceScene& sc, const Cache& c, Body&& body) {
     const uint32_t cached = min(sc.n_boxes, kBoxCache);
     for (uint32_t o = 0; o < cached; o++) body(c.box_min[o], c.box_max[o]);
-    for (uint32_t o = cached; o < sc.n_boxes; o++) body(sc.box_min[o], sc.box_max[o]);
+    if constexpr (!Cache::kFits)
+        for (uint32_t o = cached; o < sc.n_boxes; o++) body(sc.box_min[o], sc.box_max[o]);
 }
 
 // One sphere of the reference's scan (get_distance, src/raytrace.cu:59-84)
@@ -365,8 +378,8 @@ __device__ __forceinline__ void sphere_step_shadow(float b, float n2, float R, u
 }
 
 // Nearest sphere along a ray (reference get_distance, src/raytrace.cu:53-87).
-template <class M = ExactMath>
-__device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start, int& id) {
+template <class M = ExactMath, class Cache>
+__device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, const Cache& c, V3 ray, V3 start, int& id) {
     float min_dist = INFINITY;
     for_each_sphere(sc, c, [&](uint32_t i, float4 s) {
         const V3 oc = start - xyz(s);
@@ -377,8 +390,8 @@ __device__ __forceinline__ float nearest_sphere(const DeviceScene& sc, const Sce
 
 // The scan of a shadow ray towards a light at distance light_dist: the returned value compares with
 // light_dist (<) as nearest_sphere's does, and says nothing else (sphere_step_shadow).
-template <class M = ExactMath>
-__device__ __forceinline__ float nearest_sphere_shadow(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start, float light_dist, int& id) {
+template <class M = ExactMath, class Cache>
+__device__ __forceinline__ float nearest_sphere_shadow(const DeviceScene& sc, const Cache& c, V3 ray, V3 start, float light_dist, int& id) {
     float min_dist = INFINITY;
     const float half = 0.5f * light_dist;
     for_each_sphere(sc, c, [&](uint32_t i, float4 s) {
@@ -392,8 +405,8 @@ __device__ __forceinline__ float nearest_sphere_shadow(const DeviceScene& sc, co
 // light_dist and the bounce ray (b) of one hit: OC and its norm depend on the start only and are
 // computed once per sphere.  A ray whose flag is false keeps (inf, id); dist_a is good for the
 // comparison with light_dist only (sphere_step_shadow).
-template <class M = ExactMath>
-__device__ __forceinline__ void nearest_sphere_pair(const DeviceScene& sc, const SceneCache& c, V3 start, bool do_a, V3 ray_a,
+template <class M = ExactMath, class Cache>
+__device__ __forceinline__ void nearest_sphere_pair(const DeviceScene& sc, const Cache& c, V3 start, bool do_a, V3 ray_a,
                                                     float light_dist, float& dist_a, int& id_a, bool do_b, V3 ray_b, float& dist_b,
                                                     int& id_b) {
     dist_a = INFINITY;
@@ -491,8 +504,8 @@ __device__ __forceinline__ bool box_hit_via_verdict(V3 lo, V3 hi, V3 ray, float 
 // the ray is parallel to the slab, there is no t > 0 requirement, and the
 // verdict is min(exit) > max(entry).
 // kViaVerdict: decide by box_verdict where that is certain (fewer instructions, more registers).
-template <bool kViaVerdict = false, class M = ExactMath>
-__device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, const SceneCache& c, V3 ray, V3 start) {
+template <bool kViaVerdict = false, class M = ExactMath, class Cache>
+__device__ __forceinline__ bool any_box_hit(const DeviceScene& sc, const Cache& c, V3 ray, V3 start) {
     bool hit = false;
     for_each_box(sc, c, [&](float4 lo, float4 hi) {
         if (!hit) {
@@ -597,16 +610,16 @@ __device__ __forceinline__ void add_bounces(const Work& w, uint32_t n) {
 
 // True when the ray has to walk the triangle list (reference
 // src/raytrace.cu:103-146: with boxes enabled only after a box hit).
-template <bool kViaVerdict = false, class M = ExactMath>
-__device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, const SceneCache& c, int use_boxes, V3 ray, V3 start) {
+template <bool kViaVerdict = false, class M = ExactMath, class Cache>
+__device__ __forceinline__ bool needs_mesh(const DeviceScene& sc, const Cache& c, int use_boxes, V3 ray, V3 start) {
     if (sc.n_triangles == 0) return false;
     if (!use_boxes) return true;
     return any_box_hit<kViaVerdict, M>(sc, c, ray, start);
 }
 
 // needs_mesh for two rays that leave the same point; box - start is shared.
-template <class M = ExactMath>
-__device__ __forceinline__ void needs_mesh_pair(const DeviceScene& sc, const SceneCache& c, int use_boxes, V3 start, bool do_a, V3 ray_a,
+template <class M = ExactMath, class Cache>
+__device__ __forceinline__ void needs_mesh_pair(const DeviceScene& sc, const Cache& c, int use_boxes, V3 start, bool do_a, V3 ray_a,
                                                 bool& walk_a, bool do_b, V3 ray_b, bool& walk_b) {
     walk_a = false;
     walk_b = false;

@@ -62,7 +62,8 @@ __device__ __forceinline__ uint32_t commit_ray(const Work& w, uint32_t counter, 
 }
 
 // Nearest sphere + box test for a freshly generated ray, then commit_ray.
-__device__ __forceinline__ void launch_ray(const DeviceScene& sc, const SceneCache& cache, const Work& w, const Frame& f, uint32_t counter,
+template <class Cache>
+__device__ __forceinline__ void launch_ray(const DeviceScene& sc, const Cache& cache, const Work& w, const Frame& f, uint32_t counter,
                                            bool alive, uint32_t p, V3 start, V3 ray) {
     int sid = -1;
     float ts = INFINITY;
@@ -140,8 +141,8 @@ template <class M> __device__ __forceinline__ bool jitter_accepted(const rt_rng_
 // Every camera ray starts at the eye: the start-dependent half of the sphere test is the same for all paths
 // and is computed once per workgroup (same operations, same bits).  All threads must call it; the caller
 // synchronises the workgroup before eye_oc is read.
-template <class M>
-__device__ __forceinline__ void stage_eye(const DeviceScene& sc, const SceneCache& cache, const Frame& f, float4* eye_oc) {
+template <class M, class Cache>
+__device__ __forceinline__ void stage_eye(const DeviceScene& sc, const Cache& cache, const Frame& f, float4* eye_oc) {
     if (threadIdx.x < min(sc.n_spheres, kSphereCache)) {
         const V3 oc = mk(f.pos[0], f.pos[1], f.pos[2]) - xyz(cache.sphere[threadIdx.x]);
         eye_oc[threadIdx.x] = make_float4(oc.x, oc.y, oc.z, oc_norm2_m<M>(oc));
@@ -166,8 +167,8 @@ __device__ __forceinline__ V3 camera_ray(const Frame& f, const rt_rng_key& key, 
 }
 
 // nearest_sphere for a ray that starts at the eye, with the halves stage_eye prepared
-template <class M>
-__device__ __forceinline__ float nearest_sphere_from_eye(const DeviceScene& sc, const SceneCache& cache, const float4* eye_oc, V3 start, V3 ray, int& sid) {
+template <class M, class Cache>
+__device__ __forceinline__ float nearest_sphere_from_eye(const DeviceScene& sc, const Cache& cache, const float4* eye_oc, V3 start, V3 ray, int& sid) {
     float ts = INFINITY;
     sid = -1;
     const uint32_t cached = min(sc.n_spheres, kSphereCache);
@@ -183,12 +184,13 @@ __device__ __forceinline__ float nearest_sphere_from_eye(const DeviceScene& sc, 
     return ts;
 }
 
-template <uint32_t kPaths, class M>
+// kFits: the scene's tables fit the LDS cache (SceneCacheT): no code and no pointers for entries beyond it.
+template <uint32_t kPaths, class M, bool kFits>
 // regenerate: leave (accepted draw, walks the mesh) per path instead of the ray; the first bounce then computes the
 // camera ray again (k_shade_fast_first).  (An argument of its own: one more word in Frame costs the bounce kernels,
 // which are at the limit of their scalar registers, two dozen spills.)
 __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Frame f, int regenerate) {
-    __shared__ SceneCache cache;
+    __shared__ SceneCacheT<kFits> cache;
     __shared__ uint32_t key_kp[kPaths][kBlock], key_ks[kPaths][kBlock];
     __shared__ uint32_t accepted[kPaths][kBlock]; // first dimension of the accepted draw
     __shared__ float4 eye_oc[kSphereCache];       // per cached sphere: OC = eye - centre, |OC| * |OC|
@@ -334,8 +336,8 @@ __device__ __forceinline__ V3 reflect(V3 ray, V3 N) {
 // evaluated here (`lit`: diffuse hit), whether the path goes on (`alive`) and whether its weight
 // picks up the surface colour (`tinted`).  `ray` is the incoming direction on entry.  N comes back
 // flipped when a glass surface is left from the inside.
-template <class M = ExactMath>
-__device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const SceneCache& cache, const Frame& f, const rt_rng_key& rng,
+template <class M = ExactMath, class Cache>
+__device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Cache& cache, const Frame& f, const rt_rng_key& rng,
                                                int depth, int m, V3 P, V3& N, V3& start, V3& ray, V3 weight, V3& colour,
                                                uint32_t& dim, uint32_t& flags, bool& alive, bool& lit, bool& tinted) {
     const float4 mc = material_color(sc, cache, (uint32_t)m);
@@ -429,10 +431,11 @@ __device__ __forceinline__ void respond_to_hit(const DeviceScene& sc, const Scen
 // to the list and queue of stage depth + 1, and a wavefront writes at most the paths of its own stretch there.
 // kRegenerate (first bounce of a launch per bounce, k_generate's `regenerate`): the camera ray is computed again from what
 // k_generate left in Work::gen instead of being read back.
-template <class M, bool kContinue = false, bool kRegenerate = false>
+// kFits: the scene's tables fit the LDS cache (SceneCacheT).
+template <class M, bool kContinue = false, bool kRegenerate = false, bool kFits = false>
 __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& w, const Frame& f, int depth) {
     static_assert(!(kContinue && kRegenerate), "lanes that fetch a few paths at a time would compute their rays with a few lanes");
-    __shared__ SceneCache cache;
+    __shared__ SceneCacheT<kFits> cache;
     __shared__ float4 eye_oc[kRegenerate ? kSphereCache : 1];
     // The first bounce sees every path; later ones walk the list of paths the previous bounce
     // left alive, so that the lanes of a wavefront are all busy however many paths have ended.
@@ -731,31 +734,39 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
     } // trips
 }
 
+// The bounce kernels.  kFits: the scene's tables fit the LDS cache (every scene the reference ships; the host checks the
+// counts): no code and no pointers for entries beyond it -- k_shade_fast 2 965 -> 2 404 instructions, 170 -> 93 scalar
+// registers spilled to vector lanes, no scratch, 904 -> 850 us per headline frame.
 // (At least five wavefronts per SIMD: 96 VGPRs.  One register more would cost a fifth of the occupancy.)
+template <bool kFits>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade(DeviceScene sc, Work w, Frame f, int depth) {
-    shade_bounce<ExactMath>(sc, w, f, depth);
+    shade_bounce<ExactMath, false, false, kFits>(sc, w, f, depth);
 }
 
 // rt_options.arithmetic = 1: batches of kStaysFromPaths paths or more ...
+template <bool kFits>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast(DeviceScene sc, Work w, Frame f, int depth) {
-    shade_bounce<FastMath, true>(sc, w, f, depth);
+    shade_bounce<FastMath, true, false, kFits>(sc, w, f, depth);
 }
 
 // ... and smaller ones, which have too few wavefronts for long stretches and are not bound by memory: a launch per bounce,
 // every path of a list in a lane of its own.
+template <bool kFits>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast_each(DeviceScene sc, Work w, Frame f, int depth) {
-    shade_bounce<FastMath>(sc, w, f, depth);
+    shade_bounce<FastMath, false, false, kFits>(sc, w, f, depth);
 }
 
 // ... whose first bounce computes the camera ray again instead of reading it back (k_generate's `regenerate`)
+template <bool kFits>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_fast_first(DeviceScene sc, Work w, Frame f) {
-    shade_bounce<FastMath, false, true>(sc, w, f, 0);
+    shade_bounce<FastMath, false, true, kFits>(sc, w, f, 0);
 }
 
 // The control flow of k_shade_fast with the arithmetic of k_shade: what the tests hold against the oracle bit for bit
 // (RT_AMD_EXACT_STAYS, a validation knob; slower than k_shade, which has the registers for one trip only).
+template <bool kFits>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_shade_stays(DeviceScene sc, Work w, Frame f, int depth) {
-    shade_bounce<ExactMath, true>(sc, w, f, depth);
+    shade_bounce<ExactMath, true, false, kFits>(sc, w, f, depth);
 }
 
 // ---- scenes without triangles: the whole sample loop in registers -------
@@ -772,10 +783,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
 // the run of searches, the closer the lanes of a wavefront finish together: 3 % of a 1 000-sample frame).
 constexpr uint32_t kTraceGroup = 4, kTraceSearch = 16;
 
-template <class M>
+template <class M, bool kFits>
 __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame f, uint32_t n_samples, float4* __restrict__ sum,
                                                           float4* __restrict__ rad, uint32_t* __restrict__ cast_count) {
-    __shared__ SceneCache cache;
+    __shared__ SceneCacheT<kFits> cache;
     __shared__ uint32_t accepted[kTraceSearch][kBlock]; // first dimension of the accepted draw, per sample of the group
     __shared__ float4 eye_oc[kSphereCache];            // per cached sphere: OC = eye - centre, |OC| * |OC|
     stage_scene(sc, cache);

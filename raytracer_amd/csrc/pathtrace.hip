@@ -188,6 +188,11 @@ struct Carver {
 // Lays the work buffers for batches of up to n_paths paths and n_counters triangle stages out in
 // `arena` (null: only ws->bytes and the capacities are computed).  The cluster lists get at most
 // list_budget bytes; a triangle stage is cut into tiles of rays when that does not cover the queue.
+// The scene's tables fit the LDS cache of the path kernels (SceneCacheT): their kFits instances apply.
+bool scene_fits_cache(const DeviceScene& d) {
+    return d.n_spheres <= kSphereCache && d.n_materials <= kMatCache && d.n_lights <= kLightCache && d.n_boxes <= kBoxCache;
+}
+
 // Fewest wavefronts a long input of a kernel whose paths stay in their lanes is spread over (stretch_of).
 // (Validation knob: small frames get short stretches; RT_AMD_STRETCH_WAVES=1 gives them the longest.)
 uint32_t stretch_min_waves() {
@@ -839,6 +844,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         }
         // paths per lane: as many as still leave 2 048 workgroups (8 per CU)
         const bool fast = opt->arithmetic != 0;
+        const bool fits = scene_fits_cache(s->d);
         // The bounce kernel of the fast arithmetic.  Large batches of frames with indirect light and object boxes: paths stay
         // in their lanes while they need nothing from the triangle stage (k_shade_fast).  Otherwise a launch per bounce, the first
         // of which computes the camera rays again instead of reading them back (a frame without bounces has none).
@@ -848,23 +854,27 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         const bool stays = (fast && opt->indirect != 0 && opt->bounding_box != 0 && f.n_paths >= kStaysFromPaths) || exact_stays;
         const int regenerate = fast && !stays && opt->max_depth >= 1;
         if (f.n_paths >= 2048u * kBlock * 4)
-            hipLaunchKernelGGL((fast ? k_generate<4, FastMath> : k_generate<4, ExactMath>), dim3((f.n_paths + kBlock * 4 - 1) / (kBlock * 4)), block, 0, stream, s->d, w, f, regenerate);
+            hipLaunchKernelGGL((fast ? (fits ? k_generate<4, FastMath, true> : k_generate<4, FastMath, false>) : (fits ? k_generate<4, ExactMath, true> : k_generate<4, ExactMath, false>)), dim3((f.n_paths + kBlock * 4 - 1) / (kBlock * 4)), block, 0, stream, s->d, w, f, regenerate);
         else if (f.n_paths >= 2048u * kBlock * 2)
-            hipLaunchKernelGGL((fast ? k_generate<2, FastMath> : k_generate<2, ExactMath>), dim3((f.n_paths + kBlock * 2 - 1) / (kBlock * 2)), block, 0, stream, s->d, w, f, regenerate);
+            hipLaunchKernelGGL((fast ? (fits ? k_generate<2, FastMath, true> : k_generate<2, FastMath, false>) : (fits ? k_generate<2, ExactMath, true> : k_generate<2, ExactMath, false>)), dim3((f.n_paths + kBlock * 2 - 1) / (kBlock * 2)), block, 0, stream, s->d, w, f, regenerate);
         else
-            hipLaunchKernelGGL((fast ? k_generate<1, FastMath> : k_generate<1, ExactMath>), grid, block, 0, stream, s->d, w, f, regenerate);
+            hipLaunchKernelGGL((fast ? (fits ? k_generate<1, FastMath, true> : k_generate<1, FastMath, false>) : (fits ? k_generate<1, ExactMath, true> : k_generate<1, ExactMath, false>)), grid, block, 0, stream, s->d, w, f, regenerate);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
             if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
             if (depth == 0 && regenerate) {
-                hipLaunchKernelGGL(k_shade_fast_first, grid, block, 0, stream, s->d, w, f);
+                hipLaunchKernelGGL((fits ? k_shade_fast_first<true> : k_shade_fast_first<false>), grid, block, 0, stream, s->d, w, f);
             } else {
                 // (a wavefront of the kernels whose paths stay in their lanes takes stretch_of() paths; how many the lists
                 // of the later launches hold is not known here)
                 const uint32_t per_group = kWavesPerBlock * stretch_of(f.n_paths, f.min_waves);
                 const dim3 first_grid = stays ? dim3((f.n_paths + per_group - 1) / per_group) : grid;
-                hipLaunchKernelGGL((exact_stays && !fast ? k_shade_stays : !fast ? k_shade : stays ? k_shade_fast : k_shade_fast_each),
+                auto bounce = exact_stays && !fast ? (fits ? k_shade_stays<true> : k_shade_stays<false>)
+                              : !fast              ? (fits ? k_shade<true> : k_shade<false>)
+                              : !stays             ? (fits ? k_shade_fast_each<true> : k_shade_fast_each<false>)
+                                                   : (fits ? k_shade_fast<true> : k_shade_fast<false>);
+                hipLaunchKernelGGL(bounce,
                                    depth == 0 ? first_grid : dim3(grid.x + kShards), block, 0, stream, s->d, w, f, depth);
             }
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
@@ -961,6 +971,9 @@ int accumulate_spheres(rt_scene* s, const rt_camera* cam, const rt_options* opt,
         return RT_OK;
     };
     int rc;
+    const bool fits = scene_fits_cache(s->d);
+    auto trace = fast ? (fits ? k_trace_spheres<FastMath, true> : k_trace_spheres<FastMath, false>)
+                      : (fits ? k_trace_spheres<ExactMath, true> : k_trace_spheres<ExactMath, false>);
     if (!rad) {
         f.n_pixels = (row_end - row_begin) * cam->width;
         f.pixel_offset = row_begin * cam->width;
@@ -970,7 +983,7 @@ int accumulate_spheres(rt_scene* s, const rt_camera* cam, const rt_options* opt,
         for (uint32_t first = 0; first < n_samples; first += per_launch) {
             const uint32_t n = std::min(per_launch, n_samples - first);
             f.sample_begin = sample_begin + first;
-            hipLaunchKernelGGL((fast ? k_trace_spheres<FastMath> : k_trace_spheres<ExactMath>), dim3((f.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
+            hipLaunchKernelGGL(trace, dim3((f.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
                                reinterpret_cast<float4*>(d_sum), (float4*)nullptr, cast_count);
             if ((rc = after_launch((uint64_t)n * f.n_pixels)) != RT_OK) return rc;
         }
@@ -986,7 +999,7 @@ int accumulate_spheres(rt_scene* s, const rt_camera* cam, const rt_options* opt,
             f.sample_begin = sample_begin + first;
             f.n_paths = n * f.n_pixels;
             const uint32_t lanes = f.n_pixels * ((n + kTraceGroup - 1) / kTraceGroup);
-            hipLaunchKernelGGL((fast ? k_trace_spheres<FastMath> : k_trace_spheres<ExactMath>), dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
+            hipLaunchKernelGGL(trace, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, f, n,
                                reinterpret_cast<float4*>(d_sum), rad, cast_count);
             hipLaunchKernelGGL(k_accumulate, dim3((f.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, w, f,
                                reinterpret_cast<float4*>(d_sum));
