@@ -72,6 +72,9 @@ template <int kStride>
 struct PathField {
     float4* base;
     __device__ __forceinline__ float4& operator[](size_t i) const { return base[kStride * i]; }
+    // the float4 after it in the same record (the path kernels reach ray_d and q_d through ray_o and q_o: a pointer
+    // less to keep in scalar registers, which they are short of)
+    __device__ __forceinline__ float4& second(size_t i) const { return base[kStride * i + 1]; }
 };
 
 struct Work {
@@ -540,7 +543,7 @@ __device__ __forceinline__ uint32_t enqueue(const Work& w, uint32_t counter, uin
     if (want) {
         at = shard * w.shard_capacity + base + (uint32_t)__popcll(mask & ((1ULL << lane) - 1ULL));
         w.q_o[2 * (size_t)at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot));
-        w.q_d[2 * (size_t)at] = make_float4(ray.x, ray.y, ray.z, cutoff);
+        w.q_o[2 * (size_t)at + 1] = make_float4(ray.x, ray.y, ray.z, cutoff);
     }
     return at;
 }
@@ -572,19 +575,19 @@ __device__ __forceinline__ void finish_bounce(const Work& w, uint32_t counter, u
     if (want_a) {
         const size_t at = shard * w.shard_capacity + base_q + (uint32_t)__popcll(mask_a & below);
         w.q_o[2 * at] = make_float4(start.x, start.y, start.z, __uint_as_float(slot_a));
-        w.q_d[2 * at] = make_float4(ray_a.x, ray_a.y, ray_a.z, cutoff_a);
+        w.q_o[2 * at + 1] = make_float4(ray_a.x, ray_a.y, ray_a.z, cutoff_a);
     }
     if (alive) {
         const uint32_t index = (counter & 1u) * w.live_total + shard * w.live_capacity + base_l + (uint32_t)__popcll(mask_l & below);
         w.live[index] = entry;
         w.ray_o[index] = make_float4(start.x, start.y, start.z, ts_b);
-        w.ray_d[index] = make_float4(ray_b.x, ray_b.y, ray_b.z, __int_as_float(sid_b));
+        w.ray_o.second(index) = make_float4(ray_b.x, ray_b.y, ray_b.z, __int_as_float(sid_b));
         w.thr[index] = thr;
         w.hit[index] = kNoHit;
         if (walk_b) {
             const size_t at = shard * w.shard_capacity + base_q + n_a + (uint32_t)__popcll(mask_b & below);
             w.q_o[2 * at] = make_float4(start.x, start.y, start.z, __uint_as_float(index));
-            w.q_d[2 * at] = make_float4(ray_b.x, ray_b.y, ray_b.z, ts_b);
+            w.q_o[2 * at + 1] = make_float4(ray_b.x, ray_b.y, ray_b.z, ts_b);
         }
     }
 }

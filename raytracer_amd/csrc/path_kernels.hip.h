@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t commit_ray(const Work& w, uint32_t counter, 
                                                float ts, int sid, bool walk) {
     if (alive) {
         w.ray_o[p] = make_float4(start.x, start.y, start.z, ts);
-        w.ray_d[p] = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
+        w.ray_o.second(p) = make_float4(ray.x, ray.y, ray.z, __int_as_float(sid));
         w.hit[p] = kNoHit;
     }
     return enqueue(w, counter, wave_shard(), alive && walk, start, ray, p, ts);
@@ -539,7 +539,7 @@ __device__ __forceinline__ void shade_bounce(const DeviceScene& sc, const Work& 
         } else {
             // the whole state of the path in one round trip to memory
             rad = w.rad[p];
-            ro4 = w.ray_o[at_index], rd4 = w.ray_d[at_index], th = w.thr[at_index];
+            ro4 = w.ray_o[at_index], rd4 = w.ray_o.second(at_index), th = w.thr[at_index];
             key = w.hit[at_index];
             if (pending) {
                 first_pend = w.pend[(size_t)p * sc.n_lights];
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(kBlock) void k_probe_results(DeviceScene sc, Work w
                                                           float* __restrict__ out_abg, int32_t* __restrict__ out_visible) {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= f.n_paths) return;
-    const float4 ro4 = w.ray_o[p], rd4 = w.ray_d[p];
+    const float4 ro4 = w.ray_o[p], rd4 = w.ray_o.second(p);
     const float ts = ro4.w;
     int sid = __float_as_int(rd4.w);
     const unsigned long long key = w.hit[p];
