@@ -138,6 +138,32 @@ def test_fast_arithmetic_matches_the_references_mirror_cat_pixel_by_pixel():
     assert exact >= 0.9999 and within1 >= 0.99995 and off <= 8
 
 
+def test_the_two_routes_of_the_fast_arithmetic_give_the_same_bits():
+    """Batches of 1.5 M paths and more keep paths in their lanes from bounce to bounce (k_shade_fast); smaller ones take
+    a launch per bounce, the first of which computes the camera rays again.  Same arithmetic per path in the same order:
+    a frame rendered as one batch and as sample ranges too small for the first route must give the same sums bit for bit."""
+    from hip_mem import DeviceBuffer
+
+    s = load("mesh_scene", 512, 512, 8)  # 2.1 M paths in one batch
+    desc, cam = s.describe()
+    dev = s.upload()
+    n = cam.width * cam.height
+    for options in (dict(seed=4), dict(seed=4, max_depth=7), dict(seed=4, antialiasing=False)):
+        opt = rt.make_options(arithmetic=1, **options)
+        whole, parts = DeviceBuffer(4 * n), DeviceBuffer(4 * n)
+        st = dev.accumulate(cam, opt, 0, 8, whole.address, want_stats=True)
+        assert st.path_records < st.path_bounces or options.get("max_depth", 5) < 2  # (the batch did take the first route)
+        for b, e in [(0, 3), (3, 4), (4, 8)]:  # 0.8 M, 0.3 M, 1.0 M paths
+            dev.accumulate(cam, opt, b, e, parts.address)
+        a, p = whole.to_host(), parts.to_host()
+        assert np.array_equal(a.view(np.uint32), p.view(np.uint32)), options
+    # and the statistics say which route a frame took
+    _, big = dev.render(cam, rt.make_options(arithmetic=1, seed=4))
+    small = load("mesh_scene", 256, 256, 8)
+    _, few = small.upload().render(small.describe()[1], rt.make_options(arithmetic=1, seed=4))
+    assert big.path_records < 0.7 * big.path_bounces and few.path_records == few.path_bounces
+
+
 def test_unknown_arithmetic_is_rejected():
     s = load("simple", 16, 16, 1)
     desc, cam = s.describe()
