@@ -213,24 +213,46 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
         }
     }
     if (f.antialiasing) {
-        uint32_t r = 0, dim = 0;
+        // The accepted draw of every path of the wavefront (64 * kPaths of them).  A search takes 6.8 draws on average
+        // and several times that now and then, so the lanes do not keep the searches of their own paths: a lane that has
+        // found one takes the next path nobody has started (in slot order, by ballot and prefix count -- no atomics), and
+        // the wavefront is done after about total draws / 64 trips instead of after its unluckiest lane's kPaths searches.
+        // Which lane searches changes nothing about what is found.
+        const uint32_t lane = __lane_id(), wave_first = threadIdx.x - lane;
+        const uint32_t block_base = blockIdx.x * (kBlock * kPaths);
+        constexpr uint32_t kSlots = 64 * kPaths; // slot j of the wavefront: path block_base + (j / 64) * kBlock + wave_first + j % 64
+        auto valid = [&](uint32_t j) { return j < kSlots && block_base + (j >> 6) * kBlock + wave_first + (j & 63u) < f.n_paths; };
+        uint32_t j = lane, next = 64, dim = 0;
+        bool busy = valid(j);
         rt_rng_key key;
         key.kp = key_kp[0][threadIdx.x];
         key.ks = key_ks[0][threadIdx.x];
-        while (r < owned) {
-            if (jitter_accepted<M>(key, dim)) {
-                accepted[r][threadIdx.x] = dim;
-                r++;
-                dim = 0;
-                if (r < owned) {
-                    key.kp = key_kp[r][threadIdx.x];
-                    key.ks = key_ks[r][threadIdx.x];
-                }
-            } else {
+        for (;;) {
+            bool found = false;
+            if (busy) {
+                found = jitter_accepted<M>(key, dim);
+                if (found) accepted[j >> 6][wave_first + (j & 63u)] = dim;
                 dim += 2;
             }
+            const unsigned long long free_lanes = __ballot(!busy || found);
+            if (next >= kSlots) {
+                if (free_lanes == ~0ULL) break; // nothing left to start, nothing running
+                if (found) busy = false;
+                continue;
+            }
+            if (!busy || found) { // take the next slot nobody has started
+                j = next + (uint32_t)__popcll(free_lanes & ((1ULL << lane) - 1ULL));
+                busy = valid(j);
+                dim = 0;
+                if (busy) {
+                    key.kp = key_kp[j >> 6][wave_first + (j & 63u)];
+                    key.ks = key_ks[j >> 6][wave_first + (j & 63u)];
+                }
+            }
+            next += (uint32_t)__popcll(free_lanes);
         }
     }
+    __syncthreads(); // (the draws were found by other lanes)
     uint32_t n_casts = 0;
     for (uint32_t r = 0; r < kPaths; r++) {
         const uint32_t p = base + r * kBlock;
