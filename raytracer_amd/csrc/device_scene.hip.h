@@ -29,6 +29,8 @@ constexpr uint32_t kFusedClusterPairsMax = 100; // clusters grow with the mesh u
 constexpr uint32_t kMaxClusters = 64 * 64;  // two levels of at most 64 boxes each; larger meshes get larger clusters
 constexpr uint32_t kFusedGroup = 16;        // clusters per group at most where k_group_clusters is used ...
 constexpr uint32_t kFusedMaxGroups = 64;    // ... which is for meshes of up to 64 such groups
+constexpr size_t kThreeLevelsFromPairs = kFusedMaxGroups * kFusedGroup * kClusterPairs + 1; // triangle pairs from which a mesh gets three culling levels (clusters of 16 triangles,
+                                                 // groups of 16 clusters, up to 64 super-groups of up to 64 groups)
 constexpr size_t kClusterListBudget = size_t(24) << 30; // most bytes the per-cluster ray lists may take (of 288 GB)
 
 constexpr uint32_t kGenWalks = 0x80000000u;    // in Work::gen: the camera ray is queued for the first triangle stage

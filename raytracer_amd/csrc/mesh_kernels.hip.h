@@ -636,14 +636,69 @@ __device__ __forceinline__ void flush_hit(PendingHit& pend, unsigned long long* 
     }
 }
 
-template <int R, int T, int U>
+// The run table of k_group_clusters for meshes of more than kFusedMaxGroups groups (up to kMaxClusters of them), made once
+// per launch by ONE workgroup instead of by every workgroup of the consumer -- the counters sit on a line each, and
+// thousands of workgroups reading thousands of lines would cost more than the stage: plan[g] = runs of the groups before
+// group g, plan[n_groups] = their total, plan[n_groups + 1] = entries per run (a multiple of pass_entries, such that every
+// workgroup of a grid of consumer_grid gets about one run; the rule of k_group_clusters' own plan).
+__global__ __launch_bounds__(1024) void k_plan_runs(const uint32_t* __restrict__ grp_count, uint32_t n_groups, uint32_t consumer_grid,
+                                                    uint32_t pass_entries, uint32_t* __restrict__ plan) {
+    constexpr uint32_t kPer = kMaxClusters / 1024; // consecutive groups per thread
+    __shared__ uint32_t wave_sum[16];
+    const uint32_t t = threadIdx.x, lane = __lane_id(), wave = t >> 6;
+    uint32_t count[kPer], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        const uint32_t i = t * kPer + k;
+        count[k] = i < n_groups ? grp_count[(size_t)i * kCountStride] : 0u;
+        sum += count[k];
+    }
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) sum += __shfl_xor(sum, step);
+    if (lane == 0) wave_sum[wave] = sum;
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t v = 0; v < 16; v++) total += wave_sum[v];
+    uint32_t passes = (total + consumer_grid * pass_entries - 1) / (consumer_grid * pass_entries);
+    passes = min(max(passes, 1u), 16u);
+    const uint32_t run_entries = passes * pass_entries;
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) mine += (count[k] + run_entries - 1) / run_entries;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) {
+        const uint32_t up = __shfl_up(incl, step);
+        if ((int)lane >= step) incl += up;
+    }
+    __syncthreads(); // every thread has read the totals
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t v = 0; v < wave; v++) run += wave_sum[v];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        const uint32_t i = t * kPer + k;
+        if (i < n_groups) plan[i] = run;
+        run += (count[k] + run_entries - 1) / run_entries;
+    }
+    if (t == 1023) { // the groups past n_groups added nothing: the total
+        plan[n_groups] = run;
+        plan[n_groups + 1] = run_entries;
+    }
+}
+
+// kMany: more than kFusedMaxGroups groups (three culling levels) -- the run table comes from k_plan_runs (`plan`, read
+// from memory: a workgroup looks up the one or two runs it takes) instead of being computed by every workgroup.
+template <int R, int T, int U, bool kMany>
 __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
                                                       uint32_t n_clusters, uint32_t cluster_pairs, uint32_t n_groups,
                                                       uint32_t group_clusters, const f2* __restrict__ cl_pair,
                                                       const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                       const uint32_t* __restrict__ grp_count, const uint32_t* __restrict__ grp_list,
                                                       uint32_t list_capacity, unsigned long long* __restrict__ hit,
-                                                      uint32_t* __restrict__ cl_stat) {
+                                                      uint32_t* __restrict__ cl_stat, const uint32_t* __restrict__ plan) {
     constexpr uint32_t kPass = R * T;                    // list entries per pass
     constexpr uint32_t kWaves = T / 64;
     constexpr uint32_t kUnit = kPass / U;                // entries a scan unit looks at
@@ -651,13 +706,13 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
     __shared__ float4 ray_s[2 * kPass];                  // this pass's rays: origin + hit slot, direction + cut-off
     __shared__ uint16_t mask_s[kPass];                   // the clusters of the group each entry's ray touches
     __shared__ uint16_t refs_s[kWaves][kUnit];           // per wavefront: the entries of the unit it scans
-    __shared__ uint32_t first_run[kFusedMaxGroups + 1];  // runs of the groups before each group
+    __shared__ uint32_t first_run[kMany ? 1 : kFusedMaxGroups + 1];  // runs of the groups before each group
     __shared__ uint32_t run_entries_s, next_unit;
 
     // ---- plan: the groups' lists are cut into runs of `run_entries` entries (a multiple of kPass),
     // sized so that every workgroup of the grid gets about one run; every workgroup computes the same plan
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    if (wave == 0) {
+    if (!kMany && wave == 0) {
         const uint32_t mine = lane < n_groups ? grp_count[lane * kCountStride] : 0;
         uint32_t total = mine;
 #pragma unroll
@@ -677,17 +732,24 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
         if (lane == 0) run_entries_s = run_entries;
     }
     __syncthreads();
-    const uint32_t n_runs = first_run[n_groups], run_entries = run_entries_s;
+    const uint32_t n_runs = kMany ? plan[n_groups] : first_run[n_groups], run_entries = kMany ? plan[n_groups + 1] : run_entries_s;
     const uint32_t n_pairs = (n_tri + 1) / 2;
     const uint32_t my_pair = lane & 7u, my_ray = lane >> 3;
     const unsigned long long below = (1ULL << lane) - 1ULL;
 
     for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
         // the group this run belongs to (first_run is non-decreasing; n_groups <= 64: one ballot)
-        const uint32_t fr = lane < n_groups ? first_run[lane] : 0xffffffffu;
-        const uint32_t g = (uint32_t)__popcll(__ballot(fr <= run)) - 1u;
-        const uint32_t count = grp_count[g * kCountStride];
-        const uint32_t run_begin = (run - first_run[g]) * run_entries;
+        uint32_t g, runs_before;
+        if constexpr (kMany) {
+            g = owner_of_job(plan, n_groups, run);
+            runs_before = plan[g];
+        } else {
+            const uint32_t fr = lane < n_groups ? first_run[lane] : 0xffffffffu;
+            g = (uint32_t)__popcll(__ballot(fr <= run)) - 1u;
+            runs_before = first_run[g];
+        }
+        const uint32_t count = grp_count[(size_t)g * kCountStride];
+        const uint32_t run_begin = (run - runs_before) * run_entries;
         const uint32_t run_end = min(run_begin + run_entries, count);
         const uint32_t first_cluster = g * group_clusters; // even: a group starts a box pair
         const uint32_t boxes = min(group_clusters, n_clusters - first_cluster);
@@ -766,6 +828,20 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
             __syncthreads();
         }
     }
+}
+
+// Statistics: the triangle tests of a batch -- over all stage slots, (rays that met a cluster) x (triangles of the cluster,
+// cluster_tris except for the mesh's last one) -- added to *out.
+__global__ __launch_bounds__(kBlock) void k_count_tests(const uint32_t* __restrict__ cl_count, size_t n_entries, uint32_t n_clusters,
+                                                        uint32_t cluster_tris, uint32_t n_tri, unsigned long long* __restrict__ out) {
+    unsigned long long sum = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_entries; i += (size_t)gridDim.x * kBlock) {
+        const uint32_t c = (uint32_t)(i % n_clusters);
+        sum += (unsigned long long)cl_count[i * kCountStride] * min(cluster_tris, n_tri - c * cluster_tris);
+    }
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) sum += __shfl_xor(sum, step);
+    if (__lane_id() == 0 && sum) atomicAdd(out, sum);
 }
 
 __global__ __launch_bounds__(kBlock) void k_mesh_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,

@@ -198,8 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
     stage_eye<M>(sc, cache, f, eye_oc);
     __syncthreads();
     const uint32_t base = blockIdx.x * (kBlock * kPaths) + threadIdx.x;
-    // only this lane reads what it writes to the three arrays: no barrier needed
-    uint32_t owned = 0;
+    // the three arrays are written and read by the lanes of ONE wavefront (its 64 columns), in program order: no barrier needed
 #pragma unroll
     for (uint32_t r = 0; r < kPaths; r++) {
         const uint32_t p = base + r * kBlock;
@@ -209,7 +208,6 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
             key_kp[r][threadIdx.x] = key.kp;
             key_ks[r][threadIdx.x] = key.ks;
             accepted[r][threadIdx.x] = 0;
-            owned = r + 1; // paths are consecutive: a lane owns slots 0 .. owned-1
         }
     }
     if (f.antialiasing) {

@@ -79,6 +79,12 @@ struct WorkSet {
     uint32_t tiles = 1;        // cluster-list tiles per triangle stage
     size_t counter_words = 0;  // queue, live, cluster and group counters: one block starting at w.q_count
     size_t bytes = 0;          // size of the block
+    // three culling levels (rt_scene::n_super > 0): the lists of the super-groups, their counters (n_super per stage
+    // slot, right after w.grp_count's) and the run table k_plan_runs leaves for k_group_clusters
+    uint32_t* sup_count = nullptr;
+    uint32_t* sup_list = nullptr;
+    uint32_t* run_plan = nullptr;
+    unsigned long long* tests_sum = nullptr; // statistics: triangle tests of a batch, summed on the device (k_count_tests)
 };
 
 struct rt_scene {
@@ -90,7 +96,10 @@ struct rt_scene {
     void* work_block = nullptr;
     float4* sphere_rad = nullptr;        // per-sample colours of a scene without triangles (accumulate_spheres)
     size_t sphere_rad_paths = 0;
-    std::vector<uint32_t> cluster_tris;  // triangles per culling cluster
+    // Three culling levels (meshes of more than kFusedMaxGroups groups of clusters): super-groups of super_groups
+    // consecutive groups with the union of their bounds, at most 64 of at most 64.  0: two levels.
+    uint32_t n_super = 0, super_groups = 0;
+    const float2* sup_pair = nullptr;
     // profiling events
     std::vector<hipEvent_t> events;   // pool, reused by every call
     std::vector<char> event_tags;     // tag of the events in use, in record order
@@ -200,7 +209,7 @@ uint32_t stretch_min_waves() {
     return forced > 0 ? (uint32_t)forced : kMinStretchWaves;
 }
 
-int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, size_t list_budget, unsigned char* arena, WorkSet* ws) {
+int layout_work(const DeviceScene& d, uint32_t n_super, uint32_t n_paths, uint32_t n_counters, size_t list_budget, unsigned char* arena, WorkSet* ws) {
     const size_t nl = d.n_lights ? d.n_lights : 1;
     // a shard receives the rays of every kShards-th wavefront of a path kernel
     // (k_shade walks its list of live paths shard by shard, every shard ending in a partial workgroup:
@@ -226,14 +235,14 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     if (nc > 1) {
         // a tile is a range of 256-ray blocks; every shard may end in a partial block
         const size_t max_blocks = ((shard_capacity + kBlock - 1) / kBlock) * kShards;
-        list_capacity = list_budget / (4 * (lists_nc + ng)) / kBlock * kBlock;
+        list_capacity = list_budget / (4 * (lists_nc + ng + n_super)) / kBlock * kBlock;
         if (list_capacity > max_blocks * kBlock) list_capacity = max_blocks * kBlock;
         if (list_capacity < kBlock) list_capacity = kBlock;
         tiles = (max_blocks + list_capacity / kBlock - 1) / (list_capacity / kBlock);
     }
     const size_t slots_cl = (size_t)n_counters * tiles;
     const size_t q_words = (size_t)n_counters * kShards * kCountStride;
-    const size_t cl_words = slots_cl * nc * kCountStride, grp_words = slots_cl * ng * kCountStride;
+    const size_t cl_words = slots_cl * nc * kCountStride, grp_words = slots_cl * (ng + n_super) * kCountStride;
     const size_t live_capacity = per_shard; // a wavefront keeps at most its 64 paths, a workgroup its 256
     const size_t live_total = kShards * live_capacity; // >= n_paths: buffer 0 also holds the camera rays at the paths' own indices
     if (2 * live_total + (size_t)n_paths * nl > 0xffffffffu) { rt_set_error("batch too large for 32-bit hit slots"); return RT_ERR_INVALID; }
@@ -258,6 +267,10 @@ int layout_work(const DeviceScene& d, uint32_t n_paths, uint32_t n_counters, siz
     w.bounce_count = w.cast_count + (size_t)n_counters * kCastShards * kCountStride;
     w.cl_list = c.take<uint32_t>(lists_nc * list_capacity);
     w.grp_list = c.take<uint32_t>(ng * list_capacity);
+    ws->sup_count = w.grp_count + slots_cl * ng * kCountStride;
+    ws->sup_list = c.take<uint32_t>(n_super * list_capacity);
+    ws->run_plan = c.take<uint32_t>(n_super ? kMaxClusters + 2 : 0);
+    ws->tests_sum = c.take<unsigned long long>(1);
     w.live_total = (uint32_t)live_total;
     w.live_capacity = (uint32_t)live_capacity;
     w.shard_capacity = (uint32_t)shard_capacity;
@@ -277,9 +290,13 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
     n_counters = std::max(n_counters, s->ws.n_counters);
     free_work(s);
     size_t budget = kClusterListBudget, free_bytes = 0, total_bytes = 0;
+    if (const char* env = std::getenv("RT_AMD_LIST_GIB")) { // tuning knob
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= 128) budget = (size_t)v << 30;
+    }
     if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && free_bytes / 4 < budget) budget = free_bytes / 4;
     WorkSet ws;
-    int rc = layout_work(s->d, n_paths, n_counters, budget, nullptr, &ws);
+    int rc = layout_work(s->d, s->n_super, n_paths, n_counters, budget, nullptr, &ws);
     if (rc != RT_OK) return rc;
     void* block = nullptr;
     if (hipMalloc(&block, ws.bytes) != hipSuccess) {
@@ -287,7 +304,7 @@ int ensure_work(rt_scene* s, uint32_t n_paths, uint32_t n_counters) {
         rt_set_error("out of device memory: %zu bytes of work buffers for batches of %u paths", ws.bytes, n_paths);
         return RT_ERR_NOMEM;
     }
-    if ((rc = layout_work(s->d, n_paths, n_counters, budget, static_cast<unsigned char*>(block), &ws)) != RT_OK) {
+    if ((rc = layout_work(s->d, s->n_super, n_paths, n_counters, budget, static_cast<unsigned char*>(block), &ws)) != RT_OK) {
         (void)hipFree(block);
         return rc;
     }
@@ -365,7 +382,32 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
             auto bin64 = wider ? k_bin64<4> : wide ? k_bin64<2> : k_bin64<1>;
             const uint32_t ng = s->d.n_groups;
             uint32_t* grp_count = w.grp_count + slot * ng * kCountStride;
-            hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->d.grp_pair), ng,
+            const f2* grp_pair = reinterpret_cast<const f2*>(s->d.grp_pair);
+            static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
+            if (s->n_super) {
+                // three levels: the rays against the super-groups, each super-group's list against its groups (lists in
+                // global memory both), then the groups' lists against their clusters and the clusters' triangles
+                // (k_group_clusters, the last level in LDS), with the table of runs made once by k_plan_runs
+                uint32_t* sup_count = ws.sup_count + slot * s->n_super * kCountStride;
+                hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->sup_pair), s->n_super,
+                                   (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
+                                   tile * blocks_per_tile, blocks_per_tile, sup_count, ws.sup_list, w.list_capacity);
+                auto bin_groups = wider ? k_bin_groups<4> : wide ? k_bin_groups<2> : k_bin_groups<1>;
+                hipLaunchKernelGGL(bin_groups, dim3(bin_grid), dim3(kBlock), 0, stream, grp_pair, ng, s->n_super, s->super_groups,
+                                   (const float4*)w.q_o, (const float4*)w.q_d, (const uint32_t*)sup_count,
+                                   (const uint32_t*)ws.sup_list, grp_count, w.grp_list, w.list_capacity);
+                if ((rc = mark('M')) != RT_OK) return rc;
+                const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : batch_paths >= 6u * 1024u * 1024u ? 6144u : batch_paths >= 2u * 1024u * 1024u ? 3072u : 1024u;
+                hipLaunchKernelGGL(k_plan_runs, dim3(1), dim3(1024), 0, stream, (const uint32_t*)grp_count, ng, grid, 1024u, ws.run_plan);
+                hipLaunchKernelGGL((k_group_clusters<2, 512, 2, true>), dim3(grid), dim3(512), 0, stream,
+                                   tri2, s->d.tri_orig, s->d.n_triangles, nc,
+                                   s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
+                                   (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,
+                                   count_tests ? cl_count : (uint32_t*)nullptr, (const uint32_t*)ws.run_plan);
+                if ((rc = mark('E')) != RT_OK) return rc;
+                continue;
+            }
+            hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, grp_pair, ng,
                                (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
                                tile * blocks_per_tile, blocks_per_tile, grp_count, w.grp_list, w.list_capacity);
             if (s->d.fused_groups) {
@@ -374,13 +416,12 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
                 // 512 threads bin 1 024 list entries per pass (measured on the cat frame, 256 / 512 / 1 024 threads:
                 // 1.03 / 0.91 / 1.13 ms per frame).  Many more workgroups than fit the chip: a run is then one or
                 // two passes and the runs even out (768 / 3 072 / 6 144 workgroups: 1.20 / 0.90 / 0.87 ms).
-                static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
                 const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : batch_paths >= 6u * 1024u * 1024u ? 6144u : batch_paths >= 2u * 1024u * 1024u ? 3072u : 1024u;
-                hipLaunchKernelGGL((k_group_clusters<2, 512, 2>), dim3(grid), dim3(512), 0, stream,
+                hipLaunchKernelGGL((k_group_clusters<2, 512, 2, false>), dim3(grid), dim3(512), 0, stream,
                                    tri2, s->d.tri_orig, s->d.n_triangles, nc,
                                    s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
                                    (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,
-                                   count_tests ? cl_count : (uint32_t*)nullptr);
+                                   count_tests ? cl_count : (uint32_t*)nullptr, (const uint32_t*)nullptr);
             } else {
                 auto bin_groups = wider ? k_bin_groups<4> : wide ? k_bin_groups<2> : k_bin_groups<1>;
                 hipLaunchKernelGGL(bin_groups, dim3(bin_grid), dim3(kBlock), 0, stream, cl_pair, nc, ng, s->d.group_clusters,
@@ -506,13 +547,32 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     // triangles in k-d order, against clusters of 32 triangles and the global lists: 16 triangles per cluster at
     // 16 128: -4 %, 40 at 39 600: -21 %, 78 at 77 840: -39 %, 156 at 159 200: -27 %; 312 at 319 224: equal;
     // 624 at 638 400: +32 %).  Larger meshes get clusters of 32 triangles or more and the global lists.
-    uint32_t cluster_pairs = std::max<uint32_t>(kClusterPairs, (uint32_t)((n_pairs + kFusedMaxGroups * kFusedGroup - 1) / (kFusedMaxGroups * kFusedGroup)));
-    if (cluster_pairs > kFusedClusterPairsMax) cluster_pairs = 16;
+    // From kThreeLevelsFromPairs pairs on the clusters stay small and a third level is put on top: super-groups of about
+    // sqrt(groups) consecutive groups, binned through lists in global memory like the groups of the two-level path.
+    bool three_levels = n_pairs >= kThreeLevelsFromPairs;
+    if (const char* env = std::getenv("RT_AMD_LEVELS")) three_levels = std::atoi(env) == 3; // tuning / test knob
+    uint32_t cluster_pairs = kClusterPairs;
+    if (!three_levels) {
+        cluster_pairs = std::max<uint32_t>(kClusterPairs, (uint32_t)((n_pairs + kFusedMaxGroups * kFusedGroup - 1) / (kFusedMaxGroups * kFusedGroup)));
+        if (cluster_pairs > kFusedClusterPairsMax) cluster_pairs = 16;
+    }
     if (const char* env = std::getenv("RT_AMD_CLUSTER_PAIRS")) { // tuning / test knob: pairs per cluster
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 1 && v <= 4096) cluster_pairs = (uint32_t)v;
     }
-    while ((n_pairs + cluster_pairs - 1) / cluster_pairs > kMaxClusters) cluster_pairs *= 2;
+    while ((n_pairs + cluster_pairs - 1) / cluster_pairs > (three_levels ? kFusedGroup * kMaxClusters : kMaxClusters)) cluster_pairs *= 2;
+    // (a mesh that fits the two levels of k_group_clusters needs no third)
+    if ((n_pairs + cluster_pairs - 1) / cluster_pairs <= kFusedMaxGroups * kFusedGroup) three_levels = false;
+    uint32_t super_groups = 0, n_super = 0;
+    if (three_levels) {
+        const uint32_t groups = (uint32_t)(((n_pairs + cluster_pairs - 1) / cluster_pairs + kFusedGroup - 1) / kFusedGroup); // <= kMaxClusters
+        super_groups = 2 * (((uint32_t)std::ceil(std::sqrt((double)groups)) + 1) / 2); // even: a super-group starts a box pair
+        if (const char* env = std::getenv("RT_AMD_SUPER_GROUPS")) { // tuning / test knob
+            const long v = std::strtol(env, nullptr, 10);
+            if (v >= 2 && v <= 64 && v % 2 == 0 && (groups + v - 1) / v <= 64) super_groups = (uint32_t)v;
+        }
+        n_super = (groups + super_groups - 1) / super_groups;
+    }
     // Scan order of the triangle kernel: consecutive triangles are neighbours in
     // space, so that a cluster of them has tight bounds -- Morton order of the
     // centroids first (what tiny meshes and RT_AMD_ORDER=morton keep), refined
@@ -547,8 +607,8 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     }
     // Then a k-d ordering on top of it: the triangles are split at the median of their centroids
     // along the axis that leaves the two parts the smallest bounds, at multiples of the group size (16 clusters) while a part
-    // is larger than a group and at multiples of the cluster size below that, so that every
-    // cluster and every group of 16 consecutive clusters is a compact cell.  Clusters of
+    // is larger than a group (of the super-group size while it is larger than that) and at multiples of the cluster size below that, so that every
+    // cluster and every group of 16 consecutive clusters (and every super-group) is a compact cell.  Clusters of
     // consecutive Morton codes straddle the curve's jumps; the cells' bounds are tighter, so a ray
     // touches fewer of them (cat mesh, headline frame: 32 instead of 63 triangle tests per path).
     const char* order_env = std::getenv("RT_AMD_ORDER"); // test knob, read at every upload
@@ -562,13 +622,14 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
                 cen[3 * (size_t)i + a] = c == c ? c : 0.f; // NaN coordinates sort as 0
             }
         const size_t cluster_tris = 2 * (size_t)cluster_pairs, group_tris = kFusedGroup * cluster_tris;
+        const size_t super_tris = three_levels ? super_groups * group_tris : ~size_t(0);
         std::vector<std::pair<size_t, size_t>> todo{{0, d->n_triangles}};
         while (!todo.empty()) {
             const size_t lo = todo.back().first, hi = todo.back().second;
             todo.pop_back();
             const size_t range = hi - lo;
             if (range <= cluster_tris) continue;
-            const size_t unit = range > group_tris ? group_tris : cluster_tris;
+            const size_t unit = range > super_tris ? super_tris : range > group_tris ? group_tris : cluster_tris;
             const size_t units = (range + unit - 1) / unit;
             const size_t mid = lo + (units / 2) * unit;
             // the axis whose median split gives the two parts the smallest total surface area of their bounds
@@ -621,12 +682,10 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     }
     const uint32_t n_clusters = (uint32_t)((n_pairs + cluster_pairs - 1) / cluster_pairs);
     std::vector<float4> cl_min(n_clusters), cl_max(n_clusters);
-    std::vector<uint32_t> cluster_tris(n_clusters, 0);
     for (uint32_t c = 0; c < n_clusters; c++) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         const size_t begin = (size_t)c * cluster_pairs * 2;
         const size_t end = std::min<size_t>(begin + (size_t)cluster_pairs * 2, d->n_triangles);
-        cluster_tris[c] = (uint32_t)(end - begin);
         for (size_t pos = begin; pos < end; pos++)
             for (int k = 0; k < 3; k++) {
                 const float* v = d->vertices + 3 * d->tri_v[3 * order[pos] + k];
@@ -656,7 +715,7 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     // clusters: groups of kFusedGroup clusters, binned and scanned by one kernel (k_group_clusters).
     // Beyond: about sqrt(n) groups of sqrt(n) clusters (an even number, so that a group starts a box
     // pair), at most 64 of at most 64, with per-cluster lists in global memory.
-    const bool fused = n_clusters > 1 && n_clusters <= kFusedMaxGroups * kFusedGroup;
+    const bool fused = n_clusters > 1 && (n_clusters <= kFusedMaxGroups * kFusedGroup || three_levels);
     uint32_t group_clusters = fused ? kFusedGroup : 2 * (((uint32_t)std::ceil(std::sqrt((double)n_clusters)) + 1) / 2);
     if (const char* env = std::getenv("RT_AMD_GROUP_CLUSTERS")) { // tuning / test knob
         const long v = std::strtol(env, nullptr, 10);
@@ -676,6 +735,23 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
         for (int k = 0; k < 6; k++) {
             float2& dst = grp_pair[6 * (size_t)(g / 2) + k];
             if (g & 1) dst.y = v[k]; else dst.x = v[k];
+        }
+    }
+    // Three levels: super-groups of consecutive groups, the union of their clusters' bounds.
+    std::vector<float2> sup_pair(6 * (((size_t)n_super + 1) / 2), make_float2(0.f, 0.f));
+    for (uint32_t u = 0; u < n_super; u++) {
+        float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        const uint32_t per = super_groups * group_clusters;
+        for (uint32_t c = u * per; c < std::min(n_clusters, (u + 1) * per); c++) {
+            const float lo[3] = {cl_min[c].x, cl_min[c].y, cl_min[c].z}, hi[3] = {cl_max[c].x, cl_max[c].y, cl_max[c].z};
+            for (int a = 0; a < 3; a++) {
+                if (lo[a] < v[a]) v[a] = lo[a];
+                if (hi[a] > v[3 + a]) v[3 + a] = hi[a];
+            }
+        }
+        for (int k = 0; k < 6; k++) {
+            float2& dst = sup_pair[6 * (size_t)(u / 2) + k];
+            if (u & 1) dst.y = v[k]; else dst.x = v[k];
         }
     }
     std::vector<float4> box_min(d->n_boxes), box_max(d->n_boxes), light(d->n_lights);
@@ -698,11 +774,12 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     s->d.n_groups = n_groups;
     s->d.group_clusters = group_clusters;
     s->d.fused_groups = fused ? 1u : 0u;
-    s->cluster_tris = cluster_tris;
+    s->n_super = n_super;
+    s->super_groups = super_groups;
     if ((rc = upload(s, sphere, &s->d.sphere)) || (rc = upload(s, sphere_mat, &s->d.sphere_mat)) ||
         (rc = upload(s, mat_color, &s->d.mat_color)) || (rc = upload(s, mat_ior, &s->d.mat_ior)) ||
         (rc = upload(s, geom, &s->d.tri_geom)) || (rc = upload(s, pair, &s->d.tri_pair)) || (rc = upload(s, orig, &s->d.tri_orig)) ||
-        (rc = upload(s, cl_pair, &s->d.cl_pair)) || (rc = upload(s, grp_pair, &s->d.grp_pair)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
+        (rc = upload(s, cl_pair, &s->d.cl_pair)) || (rc = upload(s, grp_pair, &s->d.grp_pair)) || (rc = upload(s, sup_pair, &s->sup_pair)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
         (rc = upload(s, box_min, &s->d.box_min)) || (rc = upload(s, box_max, &s->d.box_max)) ||
         (rc = upload(s, light, &s->d.light))) {
         rt_scene_free(s);
@@ -799,8 +876,9 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
     f.count_casts = stats != nullptr;
     const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
     f.prune_zero_terms = opt->cluster_culling != 0;
-    const size_t cl_words = cull && stats ? (size_t)n_counters * ws.tiles * s->d.n_clusters * kCountStride : 0;
-    std::vector<uint32_t> cl_counts(cl_words);
+    // (rays on a cluster's list) x (triangles of the cluster), summed on the device: a large mesh has tens of thousands of
+    // counters, a line each, per stage and tile
+    const size_t cl_entries = cull && stats ? (size_t)n_counters * ws.tiles * s->d.n_clusters : 0;
     uint64_t tests = 0;
     if (stats || deferred) { // (a call without marks leaves those of an earlier call alone)
         s->event_tags.clear();
@@ -835,7 +913,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             if (cull) {
                 const size_t slots = (size_t)n_counters * ws.tiles * kCountStride * sizeof(uint32_t);
                 HIP_TRY(hipMemsetAsync(w.cl_count, 0, slots * s->d.n_clusters, stream));
-                if (s->d.n_groups) HIP_TRY(hipMemsetAsync(w.grp_count, 0, slots * s->d.n_groups, stream));
+                if (s->d.n_groups) HIP_TRY(hipMemsetAsync(w.grp_count, 0, slots * (s->d.n_groups + s->n_super), stream)); // (the super-groups' counters follow)
             }
         }
         if (stats) {
@@ -895,7 +973,13 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             HIP_TRY(hipMemcpyAsync(live_counts.data(), w.live_count, live_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(bounce_counts.data(), w.bounce_count, bounce_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(cast_counts.data(), w.cast_count, cast_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            if (cull) HIP_TRY(hipMemcpyAsync(cl_counts.data(), w.cl_count, cl_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            unsigned long long batch_tests = 0;
+            if (cull) {
+                HIP_TRY(hipMemsetAsync(ws.tests_sum, 0, sizeof(unsigned long long), stream));
+                hipLaunchKernelGGL(k_count_tests, dim3((unsigned)std::min<size_t>((cl_entries + kBlock - 1) / kBlock, 1024)), block, 0, stream,
+                                   (const uint32_t*)w.cl_count, cl_entries, s->d.n_clusters, 2 * s->d.cluster_pairs, s->d.n_triangles, ws.tests_sum);
+                HIP_TRY(hipMemcpyAsync(&batch_tests, ws.tests_sum, sizeof batch_tests, hipMemcpyDeviceToHost, stream));
+            }
             HIP_TRY(hipStreamSynchronize(stream));
             uint64_t batch_rays = 0;
             for (size_t i = 0; i < counts.size(); i += kCountStride) batch_rays += counts[i];
@@ -907,7 +991,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             for (int d = 1; d < opt->max_depth; d++)
                 for (uint32_t shard = 0; shard < kShards; shard++) path_records += live_counts[((size_t)d * kShards + shard) * kCountStride];
             if (cull) {
-                for (size_t i = 0; i < cl_words; i += kCountStride) tests += (uint64_t)cl_counts[i] * s->cluster_tris[(i / kCountStride) % s->d.n_clusters];
+                tests += batch_tests;
             } else {
                 tests += batch_rays * s->d.n_triangles;
             }
@@ -1107,7 +1191,7 @@ extern "C" int rt_accumulate_static(rt_scene* s, const rt_camera* cam, const rt_
     for (;;) {
         shape = batch_shape(cam->width, cam->height, sample_end - sample_begin, max_paths);
         const uint64_t n = (uint64_t)shape.per_batch * shape.rows_per_chunk * cam->width;
-        if (n <= kMaxPathsPerBatch && layout_work(s->d, (uint32_t)n, n_counters, kStaticWorkBytes / 2, nullptr, &ws) == RT_OK &&
+        if (n <= kMaxPathsPerBatch && layout_work(s->d, s->n_super, (uint32_t)n, n_counters, kStaticWorkBytes / 2, nullptr, &ws) == RT_OK &&
             ws.bytes <= kStaticWorkBytes)
             break;
         if (n <= cam->width) {
@@ -1117,7 +1201,7 @@ extern "C" int rt_accumulate_static(rt_scene* s, const rt_camera* cam, const rt_
         }
         max_paths = (uint32_t)std::max<uint64_t>(n / 2, cam->width);
     }
-    if ((rc = layout_work(s->d, ws.paths, n_counters, kStaticWorkBytes / 2, area, &ws)) != RT_OK) return rc;
+    if ((rc = layout_work(s->d, s->n_super, ws.paths, n_counters, kStaticWorkBytes / 2, area, &ws)) != RT_OK) return rc;
     return accumulate_batches(s, ws, shape, cam, opt, sample_begin, sample_end, 0, cam->height, d_sum,
                               static_cast<hipStream_t>(stream_), nullptr, false);
 }
@@ -1212,7 +1296,7 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
         hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, w, f, (const float*)d_a, (const float*)d_b, as_segments);
         const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
         if (cull && hipMemset(w.cl_count, 0, (size_t)2 * s->ws.tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
-        if (cull && s->d.n_groups && hipMemset(w.grp_count, 0, (size_t)2 * s->ws.tiles * s->d.n_groups * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        if (cull && s->d.n_groups && hipMemset(w.grp_count, 0, (size_t)2 * s->ws.tiles * (s->d.n_groups + s->n_super) * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         if (launch_mesh(s, s->ws, 0, nullptr, false, cull, n, false) != RT_OK) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }

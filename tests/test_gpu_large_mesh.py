@@ -1,5 +1,5 @@
-"""Meshes larger than the shipped cat model: more than 64 culling clusters (the general binning
-kernel) and more than 65 536 triangles (clusters grow beyond 64 triangles)."""
+"""Meshes larger than the shipped cat model: more than 64 culling clusters (two culling levels), more than
+1 024 (from 16 385 triangles on: three levels, or -- RT_AMD_LEVELS=2 -- two with larger clusters)."""
 import os
 import sys
 
@@ -28,8 +28,11 @@ def scene_with_mesh(tmp_path, n_lat, n_lon, material, width, height, spp):
     return s, len(t)
 
 
-@pytest.mark.parametrize("n_lat,n_lon,material", [(32, 62, rt.DIFFUSE), (100, 200, rt.DIFFUSE), (60, 90, rt.GLASS), (200, 400, rt.MIRROR)])
-def test_large_mesh_culled_equals_exhaustive_equals_oracle(tmp_path, n_lat, n_lon, material):
+@pytest.mark.parametrize("n_lat,n_lon,material,levels", [(32, 62, rt.DIFFUSE, None), (100, 200, rt.DIFFUSE, None), (100, 200, rt.DIFFUSE, "2"),
+                                                         (60, 90, rt.GLASS, None), (200, 400, rt.MIRROR, None), (200, 400, rt.MIRROR, "2")])
+def test_large_mesh_culled_equals_exhaustive_equals_oracle(tmp_path, monkeypatch, n_lat, n_lon, material, levels):
+    if levels:
+        monkeypatch.setenv("RT_AMD_LEVELS", levels)
     s, n_tri = scene_with_mesh(tmp_path, n_lat, n_lon, material, 96, 80, 2)
     desc, cam = s.describe()
     assert desc.n_triangles == n_tri == 2 * n_lat * n_lon - 2 * n_lon
@@ -44,7 +47,9 @@ def test_large_mesh_culled_equals_exhaustive_equals_oracle(tmp_path, n_lat, n_lo
     assert same_bits(culled.reshape(-1, 3)[pixels], ref)
 
 
-def test_large_mesh_probes(tmp_path):
+@pytest.mark.parametrize("levels", ["2", "3"])
+def test_large_mesh_probes(tmp_path, monkeypatch, levels):
+    monkeypatch.setenv("RT_AMD_LEVELS", levels)
     s, _ = scene_with_mesh(tmp_path, 100, 200, rt.DIFFUSE, 32, 32, 1)
     desc, _ = s.describe()
     dev = s.upload()

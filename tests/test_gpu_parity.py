@@ -189,6 +189,30 @@ def test_other_cluster_sizes_give_the_same_image(pairs, monkeypatch):
     assert np.array_equal(tid, rtid) and same_bits(t, rt_)
 
 
+@pytest.mark.parametrize("super_groups", [None, "2", "64"])
+def test_three_culling_levels_give_the_same_image(super_groups, monkeypatch):
+    """Meshes of more than 1 024 clusters get a third level (super-groups of groups of clusters, k_plan_runs and the
+    many-groups instance of k_group_clusters).  Forced onto the cat with one pair per cluster: 1 977 clusters in 124
+    groups, in 11 super-groups of 12 by default, in 62 of 2, in 2 of 64."""
+    monkeypatch.setenv("RT_AMD_LEVELS", "3")
+    monkeypatch.setenv("RT_AMD_CLUSTER_PAIRS", "1")
+    if super_groups:
+        monkeypatch.setenv("RT_AMD_SUPER_GROUPS", super_groups)
+    s = variant("mesh_scene", "glass", 72, 56, 3)
+    desc, cam = s.describe()
+    dev = s.upload()
+    opt = rt.make_options(seed=23)
+    img, st = dev.render(cam, opt)
+    ref, _ = ob.render_image(desc, cam, ob.from_rt_options(opt))
+    assert same_bits(img, ref)
+    full, st_full = dev.render(cam, rt.make_options(seed=23, cluster_culling=False))
+    assert same_bits(img, full) and 0 < st.triangle_tests < st_full.triangle_tests / 8
+    o, d = rays_for(None, 30000, 5)
+    t, sid, tid, abg = dev.cast(opt, o, d)
+    rt_, rsid, rtid, rabg = ob.cast(desc, ob.from_rt_options(opt), o, d)
+    assert np.array_equal(tid, rtid) and same_bits(t, rt_)
+
+
 @pytest.mark.parametrize("pairs", ["1", "8", "64", "1000"])
 def test_axis_parallel_rays_through_the_cluster_filter(pairs, monkeypatch):
     """Rays with one or two exactly-zero direction components, cast without the object boxes, so that

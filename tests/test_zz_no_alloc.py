@@ -68,6 +68,14 @@ def test_static_work_area_gives_the_sums_of_rt_accumulate():
     assert np.array_equal(whole.to_host().view(np.uint32), parts.to_host().view(np.uint32))
 
 
+def test_static_work_area_with_three_culling_levels(monkeypatch):
+    """The third culling level takes its lists, counters and run table from the same work area."""
+    rt.init(0)
+    monkeypatch.setenv("RT_AMD_LEVELS", "3")
+    monkeypatch.setenv("RT_AMD_CLUSTER_PAIRS", "1")
+    both_ways(load("mesh_scene", 96, 64, 3), rt.make_options(seed=67), 0, 3)
+
+
 def test_static_work_area_ignores_the_profile_option():
     """Timing marks would create events (an allocation): the call takes none, whatever rt_options.profile says."""
     rt.init(0)
