@@ -1,4 +1,4 @@
-// mesh_kernels.hip.h -- the triangle kernels: exhaustive scan (k_mesh) and cluster culling (k_bin64, then k_group_clusters, or k_bin_groups + k_mesh_clusters for very large meshes).
+// mesh_kernels.hip.h -- the triangle kernels: exhaustive scan (k_mesh) and cluster culling (k_bin64, then k_group_clusters; with k_bin_groups and k_plan_runs between them for meshes of more than 1 024 clusters).
 // Part of the device half of librt_amd.so; included by pathtrace.hip only.
 #pragma once
 
@@ -338,9 +338,12 @@ __global__ __launch_bounds__(kBlock) void k_mesh(const f2* __restrict__ tri2, co
 //   k_group_clusters   meshes of up to 64 groups of 16 clusters: a workgroup
 //                      bins a stretch of one group's list into that group's
 //                      clusters in LDS and scans the clusters' triangles itself
-//   k_bin_groups +     larger meshes (groups of up to 64 clusters): per-cluster
-//   k_mesh_clusters    lists in global memory, job offsets from the list
-//                      lengths (plan_jobs), the same pair scan per job
+//   three levels       more than 1 024 clusters: k_bin64 against up to 64 super-groups
+//                      of groups, k_bin_groups (a super-group's list against its
+//                      groups -> per-group lists), k_plan_runs, k_group_clusters
+//   k_bin_groups +     (RT_AMD_LEVELS=2: large meshes on two levels, groups of up to 64
+//   k_mesh_clusters    clusters) per-cluster lists in global memory, job offsets from
+//                      the list lengths (plan_jobs), the same pair scan per job
 //
 // The image is the exhaustive scan's, bit for bit, unless the reference's own
 // rounding makes it accept a triangle for a ray that misses the triangle by

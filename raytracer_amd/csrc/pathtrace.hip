@@ -13,7 +13,8 @@
 //   k_generate           camera sample, nearest sphere, box test
 //   for each bounce:
 //     triangle stage     the queued rays against the mesh: k_mesh, or
-//                        k_bin64 and k_group_clusters (very large meshes: k_bin_groups, k_mesh_clusters)
+//                        k_bin64 and k_group_clusters (more than 1 024 clusters: k_bin64, k_bin_groups,
+//                        k_plan_runs, k_group_clusters -- three culling levels)
 //     k_shade            hit selection, material response, shadow rays,
 //                        next ray, nearest sphere, box test
 //   triangle stage       shadow rays of the last bounce
@@ -349,8 +350,10 @@ int mark_event(rt_scene* s, hipStream_t stream, char tag) {
 
 // One k_mesh stage: the queued rays of `counter` against the mesh, either by
 // the exhaustive scan or through the cluster lists.
+// ray_bound: most rays the stage's queue can hold (0: unknown) -- the camera rays of a batch are at most its paths --,
+// which spares a mesh whose lists need several tiles per stage the launches of tiles that are certainly empty.
 int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t stream, bool profile, bool cull, uint32_t batch_paths,
-                bool count_tests) {
+                bool count_tests, size_t ray_bound = 0) {
     const Work& w = ws.w;
     if (s->d.n_triangles == 0) return RT_OK;
     auto mark = [&](char tag) -> int { return profile ? mark_event(s, stream, tag) : RT_OK; };
@@ -360,7 +363,10 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
     if (cull && s->d.n_clusters > 1) {
         const uint32_t nc = s->d.n_clusters;
         const uint32_t blocks_per_tile = w.list_capacity / kBlock;
-        for (uint32_t tile = 0; tile < ws.tiles; tile++) {
+        uint32_t tiles = ws.tiles;
+        if (ray_bound) // every shard may end in a partial block
+            tiles = (uint32_t)std::min<size_t>(tiles, ((ray_bound + kBlock - 1) / kBlock + kShards + blocks_per_tile - 1) / blocks_per_tile);
+        for (uint32_t tile = 0; tile < tiles; tile++) {
             const size_t slot = (size_t)counter * ws.tiles + tile;
             uint32_t* cl_count = w.cl_count + slot * nc * kCountStride;
             if ((rc = mark('B')) != RT_OK) return rc;
@@ -541,12 +547,10 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     const size_t n_pairs = ((size_t)d->n_triangles + 1) / 2;
     // Clusters of consecutive pairs and their bounds, padded by 0.05 plus a
     // thousandth of the cluster's diagonal.
-    // Cluster size: as many clusters as k_group_clusters takes (64 groups of 16), of at least 16 triangles -- up to
-    // about 200 000 triangles the kernel that keeps the second level in LDS beats the one with per-cluster lists
-    // in global memory even though its clusters grow with the mesh (measured on meshes of 3 844 to 638 400
-    // triangles in k-d order, against clusters of 32 triangles and the global lists: 16 triangles per cluster at
-    // 16 128: -4 %, 40 at 39 600: -21 %, 78 at 77 840: -39 %, 156 at 159 200: -27 %; 312 at 319 224: equal;
-    // 624 at 638 400: +32 %).  Larger meshes get clusters of 32 triangles or more and the global lists.
+    // Cluster size: 16 triangles.  Up to 1 024 clusters are the two levels of k_group_clusters (64 groups of 16).
+    // (RT_AMD_LEVELS=2 keeps larger meshes on two levels as well: the clusters then grow with the mesh up to about
+    // 200 000 triangles, and beyond that clusters of 32 triangles or more get per-cluster lists in global memory --
+    // measured against three levels: 39 600 triangles 5.4 against 4.3 ms, 638 400 triangles 14.7 against 7.1 ms.)
     // From kThreeLevelsFromPairs pairs on the clusters stay small and a third level is put on top: super-groups of about
     // sqrt(groups) consecutive groups, binned through lists in global memory like the groups of the two-level path.
     bool three_levels = n_pairs >= kThreeLevelsFromPairs;
@@ -939,7 +943,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             hipLaunchKernelGGL((fast ? (fits ? k_generate<1, FastMath, true> : k_generate<1, FastMath, false>) : (fits ? k_generate<1, ExactMath, true> : k_generate<1, ExactMath, false>)), grid, block, 0, stream, s->d, w, f, regenerate);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
-            if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
+            if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr, depth == 0 ? f.n_paths : 0)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
             if (depth == 0 && regenerate) {
                 hipLaunchKernelGGL((fits ? k_shade_fast_first<true> : k_shade_fast_first<false>), grid, block, 0, stream, s->d, w, f);

@@ -173,7 +173,7 @@ def test_culled_and_exhaustive_frames_are_identical_at_full_size():
 def test_other_cluster_sizes_give_the_same_image(pairs, monkeypatch):
     """1 pair per cluster gives the cat 1 977 clusters: more than the kernel with the second level in LDS takes,
     so the per-cluster lists in global memory (k_bin_groups + k_mesh_clusters), which meshes of more than about
-    200 000 triangles use.  4 and 8 pairs give more than 64 clusters (two levels, second one in LDS), 64 fewer,
+    200 000 triangles use when they are kept on two culling levels.  4 and 8 pairs give more than 64 clusters (two levels, second one in LDS), 64 fewer,
     1000 two clusters."""
     monkeypatch.setenv("RT_AMD_CLUSTER_PAIRS", pairs)
     s = variant("mesh_scene", "glass", 72, 56, 3)
