@@ -190,6 +190,73 @@ __device__ __forceinline__ void pair_hits(const PairData& p, bool live, float ox
     }
 }
 
+// The division-free filter of pair_hits alone: c0 / c1 say whether the ray's line may meet triangle 0 / 1 of the pair
+// (the same packed arithmetic, so the same verdicts).
+__device__ __forceinline__ void pair_filter(const PairData& p, bool live, float ox, float oy, float oz, float ux, float uy, float uz,
+                                            bool& c0, bool& c1) {
+    const f2 Ax = p.v[0], Ay = p.v[1], Az = p.v[2];
+    const f2 e1x = p.v[3], e1y = p.v[4], e1z = p.v[5];
+    const f2 e2x = p.v[6], e2y = p.v[7], e2z = p.v[8];
+    const f2 Nx = p.v[9], Ny = p.v[10], Nz = p.v[11];
+    const f2 aox = Ax - ox, aoy = Ay - oy, aoz = Az - oz;
+    const f2 qx = aoy * uz - aoz * uy;
+    const f2 qy = aoz * ux - aox * uz;
+    const f2 qz = aox * uy - aoy * ux;
+    const f2 d = (ux * Nx + uy * Ny) + uz * Nz;
+    const f2 nb = (e2x * qx + e2y * qy) + e2z * qz; // e2 . q
+    const f2 ng = (e1x * qx + e1y * qy) + e1z * qz; // e1 . q
+    f2 rcp;
+    rcp.x = __builtin_amdgcn_rcpf(d.x);
+    rcp.y = __builtin_amdgcn_rcpf(d.y);
+    const f2 b_ = nb * rcp;
+    const f2 g_ = -ng * rcp;
+    const f2 a_ = (1.f - b_) - g_;
+    const float lo0 = fminf(fminf(a_.x, b_.x), g_.x);
+    const float lo1 = fminf(fminf(a_.y, b_.y), g_.y);
+    c0 = live && !(lo0 < -1e-5f);
+    c1 = live && !(lo1 < -1e-5f);
+}
+
+// One (ray, triangle) that pair_filter let through, decided the way pair_hits decides it: the same expressions on
+// one triangle's twelve numbers (t[0..12): A.xyz, e1.xyz, e2.xyz, N.xyz) in unpacked arithmetic, which rounds like
+// the packed one.  emit(numerator, denominator) is called when the reference's test accepts the triangle with
+// 0 < t = numerator / denominator < cutoff.
+template <typename Emit>
+__device__ __forceinline__ void triangle_hit(const float (&t)[12], bool live, float ox, float oy, float oz, float ux, float uy, float uz,
+                                             float cutoff, Emit&& emit) {
+    const float aox = t[0] - ox, aoy = t[1] - oy, aoz = t[2] - oz;
+    const float qx = aoy * uz - aoz * uy;
+    const float qy = aoz * ux - aox * uz;
+    const float qz = aox * uy - aoy * ux;
+    const float d = (ux * t[9] + uy * t[10]) + uz * t[11];
+    const float nb = (t[6] * qx + t[7] * qy) + t[8] * qz; // e2 . q
+    const float ng = (t[3] * qx + t[4] * qy) + t[5] * qz; // e1 . q
+    const float rcp = __builtin_amdgcn_rcpf(d);
+    const float b_ = nb * rcp;
+    const float g_ = -ng * rcp;
+    const float a_ = (1.f - b_) - g_;
+    const float lo = fminf(fminf(a_, b_), g_);
+    if (live && !(lo < -1e-5f)) {
+        const float aon = (aox * t[9] + aoy * t[10]) + aoz * t[11];
+        bool inside = lo >= 1e-5f; // the exact barycentrics are certainly positive
+        if (!inside) {             // near an edge (or NaN): the reference's own quotients decide
+            const float beta = nb / d;
+            const float gamma = -ng / d;
+            const float alpha = 1.f - beta - gamma;
+            inside = alpha >= 0 && beta >= 0 && gamma >= 0;
+        }
+        if (inside) {
+            const float t_ = aon * rcp;
+            bool valid = t_ * 1.000002f < cutoff && t_ > 1e-30f;
+            if (!valid && !(t_ > cutoff * 1.000002f || t_ < 0.f)) {
+                const float tt = aon / d;
+                valid = tt > 0 && tt < cutoff;
+            }
+            if (valid) emit(aon, d);
+        }
+    }
+}
+
 // Lane l of every wavefront holds shard l's ray count and the number of
 // 256-ray blocks in the shards before it.
 struct ShardMap {
@@ -709,6 +776,11 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
     __shared__ float4 ray_s[2 * kPass];                  // this pass's rays: origin + hit slot, direction + cut-off
     __shared__ uint16_t mask_s[kPass];                   // the clusters of the group each entry's ray touches
     __shared__ uint16_t refs_s[kWaves][kUnit];           // per wavefront: the entries of the unit it scans
+    // per wavefront: the (ray, triangle) candidates the filter has let through and nobody has decided yet --
+    // entry of the pass | (pair within the group, triangle of the pair) << 10
+    constexpr uint32_t kCandCap = 256;
+    static_assert(kPass <= 1024, "a candidate keeps its entry of the pass in ten bits");
+    __shared__ uint32_t cand_s[kWaves][kCandCap];
     __shared__ uint32_t first_run[kMany ? 1 : kFusedMaxGroups + 1];  // runs of the groups before each group
     __shared__ uint32_t run_entries_s, next_unit;
 
@@ -781,9 +853,30 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
             __syncthreads();
 
             // ---- scan: (cluster, part of the pass) units.  A wavefront works as 8 pairs x 8 rays.
+            // The filter of a trip lets a few of its 128 (ray, triangle) tests through -- the ray's line meets the
+            // triangle -- in nearly every trip; deciding them on the spot would run the rest of the test with a
+            // handful of lanes per trip.  They are queued instead and decided 64 at a time, a lane each.
             const uint32_t n_units = U * boxes;
+            const uint32_t group_first_pair = first_cluster * cluster_pairs;
             PendingHit pend;
             pend.num = 0.f; pend.den = 1.f; pend.orig = 0xffffffffu; pend.slot = 0;
+            uint32_t n_cand = 0;
+            auto decide = [&](uint32_t at, bool on) { // the candidate at cand_s[wave][at]
+                const uint32_t code = cand_s[wave][at];
+                const uint32_t e = code & 1023u, th = code >> 10;
+                const size_t tri = 2 * (size_t)group_first_pair + th;
+                const float4 o4 = ray_s[2 * e], d4 = ray_s[2 * e + 1];
+                const float* __restrict__ g = reinterpret_cast<const float*>(tri2) + 24 * (tri >> 1) + (tri & 1u);
+                float t[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) t[k] = g[2 * k];
+                const uint32_t og = tri_orig[tri];
+                triangle_hit(t, on, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, d4.w, [&](float num, float den) {
+                    flush_hit(pend, hit);
+                    pend.num = num; pend.den = den; pend.slot = __float_as_uint(o4.w);
+                    pend.orig = og;
+                });
+            };
             for (;;) {
                 uint32_t unit = 0;
                 if (lane == 0) unit = atomicAdd(&next_unit, 1u);
@@ -814,11 +907,24 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
                         const uint32_t k = k0 + my_ray;
                         const uint32_t e = refs_s[wave][min(k, n - 1u)];
                         const float4 o4 = ray_s[2 * e], d4 = ray_s[2 * e + 1];
-                        pair_hits(pd, k < n, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, d4.w, [&](int h, float num, float den) {
-                            flush_hit(pend, hit); // (rare: an earlier hit of this lane is still pending)
-                            pend.num = num; pend.den = den; pend.slot = __float_as_uint(o4.w);
-                            pend.orig = h ? orig.y : orig.x;
-                        });
+                        bool c0, c1;
+                        pair_filter(pd, k < n, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, c0, c1);
+                        const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+                        if (m0 | m1) {
+                            if (n_cand + 128u <= kCandCap) {
+                                const uint32_t code = e | ((j - group_first_pair) << 11);
+                                const uint32_t n0 = (uint32_t)__popcll(m0);
+                                if (c0) cand_s[wave][n_cand + (uint32_t)__popcll(m0 & below)] = code;
+                                if (c1) cand_s[wave][n_cand + n0 + (uint32_t)__popcll(m1 & below)] = code | 1024u;
+                                n_cand += n0 + (uint32_t)__popcll(m1);
+                            } else { // (the queue is full: a unit of many trips whose candidates come thick) decided on the spot
+                                pair_hits(pd, k < n, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, d4.w, [&](int h, float num, float den) {
+                                    flush_hit(pend, hit);
+                                    pend.num = num; pend.den = den; pend.slot = __float_as_uint(o4.w);
+                                    pend.orig = h ? orig.y : orig.x;
+                                });
+                            }
+                        }
                     }
                     chunk += 8; // clusters of more than eight pairs: the next eight
                     if (chunk > last) break;
@@ -826,7 +932,12 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
                     pd = load_pair(tri2, j);
                     orig = reinterpret_cast<const uint2*>(tri_orig)[j];
                 }
+                while (n_cand >= 64u) { // between units, when the trip's registers are free
+                    n_cand -= 64u;
+                    decide(n_cand + lane, true);
+                }
             }
+            if (n_cand) decide(min(lane, n_cand - 1u), lane < n_cand); // what is left belongs to this pass's rays
             flush_hit(pend, hit);
             __syncthreads();
         }
