@@ -908,7 +908,13 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
         f.n_paths = in_batch * n_pixels;
         f.sample_begin = sample_begin + first;
         const dim3 grid((f.n_paths + kBlock - 1) / kBlock), block(kBlock);
-        if (ws.n_counters == n_counters) { // the counters are one block: one fill
+        const size_t cl_count_words = (size_t)(w.grp_count - w.cl_count);
+        if (ws.n_counters == n_counters && s->d.fused_groups && !stats && cl_count_words >= (1u << 20)) {
+            // k_group_clusters touches the per-cluster counters for the statistics only, and a mesh of tens of thousands
+            // of clusters has hundreds of megabytes of them (a line each, per stage and tile): the blocks around them
+            HIP_TRY(hipMemsetAsync(w.q_count, 0, (size_t)(w.cl_count - w.q_count) * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(w.grp_count, 0, (ws.counter_words - (size_t)(w.grp_count - w.q_count)) * sizeof(uint32_t), stream));
+        } else if (ws.n_counters == n_counters) { // the counters are one block: one fill
             HIP_TRY(hipMemsetAsync(w.q_count, 0, ws.counter_words * sizeof(uint32_t), stream));
         } else { // a work set laid out for more bounces than this frame has: only the stages it runs
             const size_t q_bytes = (size_t)n_counters * kShards * kCountStride * sizeof(uint32_t);

@@ -9,6 +9,7 @@ import pytest
 import oracle_binding as ob
 import raytracer_amd as rt
 from helpers import SCENES, same_bits
+from hip_mem import DeviceBuffer
 
 sys.path.insert(0, os.path.join(rt.REPO_ROOT, "tools"))
 import make_mesh  # noqa: E402
@@ -64,3 +65,20 @@ def test_large_mesh_probes(tmp_path, monkeypatch, levels):
         assert (rtid >= 0).sum() > 200
         assert np.array_equal(tid, rtid) and np.array_equal(sid, rsid) and same_bits(t, rt_)
         assert same_bits(abg[rtid >= 0], rabg[rtid >= 0])
+
+
+def test_large_mesh_sums_with_and_without_statistics(tmp_path):
+    """A call without statistics leaves the per-cluster counters of a mesh of thousands of clusters alone (they feed the
+    statistics only) and clears the counters around them: the sums are those of a call with statistics."""
+    s, _ = scene_with_mesh(tmp_path, 200, 400, rt.DIFFUSE, 64, 48, 3)
+    _, cam = s.describe()
+    dev = s.upload()
+    n = cam.width * cam.height
+    opt = rt.make_options(seed=9)
+    sums = []
+    for want_stats in (True, False, False):
+        buf = DeviceBuffer(4 * n)
+        st = dev.accumulate(cam, opt, 0, 3, buf.address, want_stats=want_stats)
+        sums.append(buf.to_host().view(np.uint32).copy())
+        assert (st is not None) == want_stats and (st is None or st.triangle_tests > 0)
+    assert np.array_equal(sums[0], sums[1]) and np.array_equal(sums[0], sums[2])
