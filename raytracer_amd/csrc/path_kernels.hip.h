@@ -119,23 +119,45 @@ template <class M> __device__ __forceinline__ void jitter_m(const rt_rng_key& ke
     if constexpr (M::kExact) jitter_exact(key, dim, dx, dy); else jitter_fast(key, dim, dx, dy);
 }
 
-// Is the draw at `dim` accepted (both offsets within half a pixel, src/raytrace.cu:483-486)?  ExactMath: classified
-// with the hardware transcendentals where that is certain, by the reference's own arithmetic within 1e-4 of the limit.
-// FastMath: the hardware values are the arithmetic.
-template <class M> __device__ __forceinline__ bool jitter_accepted(const rt_rng_key& key, uint32_t dim) {
-    const float r1 = rt_rng_uniform(key, dim);
-    if (!(r1 >= 0.77f)) return false; // radius > 0.722: one offset exceeds 0.5
-    const float r2 = rt_rng_uniform(key, dim + 1);
+// One trip of the search for a path's accepted draw.  Three draws of four fail the cheap test (r1 < 0.77) and a
+// wavefront that evaluates one draw per lane and trip runs the expensive rest -- second number, logarithm, root, sine,
+// cosine -- in every trip for the quarter of its lanes that pass.  So a trip looks at the first numbers of the next
+// kJitterLook draws from `dim` on and evaluates the first of them that passes, which two lanes of three have.
+// Accepted: returns true with `dim` at that draw.  Otherwise `dim` moves past every draw the trip has settled (the
+// evaluated one and those before it, or all kJitterLook).  A draw is accepted when both offsets are within half a
+// pixel (src/raytrace.cu:483-486).  ExactMath: classified with the hardware transcendentals where that is certain, by
+// the reference's own arithmetic within 1e-4 of the limit.  FastMath: the hardware values are the arithmetic.  The
+// draws are looked at in order, so the accepted one is the first the reference's loop accepts.
+constexpr int kJitterLook = 4;
+template <class M> __device__ __forceinline__ bool jitter_search(const rt_rng_key& key, uint32_t& dim) {
+    uint32_t first = kJitterLook;
+    float r1 = 1.f;
+#pragma unroll
+    for (int i = kJitterLook - 1; i >= 0; i--) {
+        const float r = rt_rng_uniform(key, dim + 2 * i);
+        if (r >= 0.77f) { first = (uint32_t)i; r1 = r; }
+    }
+    const uint32_t d = dim + 2 * first;
+    if (first == (uint32_t)kJitterLook) { dim = d; return false; }
+    dim = d + 2;
+    const float r2 = rt_rng_uniform(key, d + 1);
     float radius;
     if constexpr (M::kExact) radius = __builtin_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1)); // -2 ln 2 * log2(r1)
     else radius = __builtin_amdgcn_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1));
     const float m = fmaxf(fabsf(radius * __builtin_amdgcn_cosf(r2)), fabsf(radius * __builtin_amdgcn_sinf(r2))); // argument in turns
-    if constexpr (!M::kExact) return !(m > 0.5f);
-    if (m < 0.4999f) return true;
-    if (m > 0.5001f) return false;
-    float dx, dy;
-    jitter_exact(key, dim, dx, dy);
-    return !(fabsf(dx) > 0.5f || fabsf(dy) > 0.5f);
+    bool ok;
+    if constexpr (!M::kExact) {
+        ok = !(m > 0.5f);
+    } else {
+        ok = m < 0.4999f;
+        if (!ok && !(m > 0.5001f)) { // within 1e-4 of the limit: the reference's own arithmetic decides
+            float dx, dy;
+            jitter_exact(key, d, dx, dy);
+            ok = !(fabsf(dx) > 0.5f || fabsf(dy) > 0.5f);
+        }
+    }
+    if (ok) dim = d;
+    return ok;
 }
 
 // Every camera ray starts at the eye: the start-dependent half of the sphere test is the same for all paths
@@ -228,9 +250,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, Work w, Fra
         for (;;) {
             bool found = false;
             if (busy) {
-                found = jitter_accepted<M>(key, dim);
+                found = jitter_search<M>(key, dim);
                 if (found) accepted[j >> 6][wave_first + (j & 63u)] = dim;
-                dim += 2;
             }
             const unsigned long long free_lanes = __ballot(!busy || found);
             if (next >= kSlots) {
@@ -845,13 +866,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_spheres(DeviceScene sc, Frame 
             uint32_t r = 0, dim = 0;
             rt_rng_key key = rt_rng_make_key(f.seed, pixel, f.sample_begin + s0);
             while (r < group) {
-                if (jitter_accepted<M>(key, dim)) {
+                if (jitter_search<M>(key, dim)) {
                     accepted[r][threadIdx.x] = dim;
                     r++;
                     dim = 0;
                     if (r < group) key = rt_rng_make_key(f.seed, pixel, f.sample_begin + s0 + r);
-                } else {
-                    dim += 2;
                 }
             }
         }
