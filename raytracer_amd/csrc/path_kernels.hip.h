@@ -128,18 +128,24 @@ template <class M> __device__ __forceinline__ void jitter_m(const rt_rng_key& ke
 // pixel (src/raytrace.cu:483-486).  ExactMath: classified with the hardware transcendentals where that is certain, by
 // the reference's own arithmetic within 1e-4 of the limit.  FastMath: the hardware values are the arithmetic.  The
 // draws are looked at in order, so the accepted one is the first the reference's loop accepts.
-constexpr int kJitterLook = 4;
+#ifndef RT_JITTER_LOOK
+#define RT_JITTER_LOOK 4
+#endif
+constexpr int kJitterLook = RT_JITTER_LOOK; // (measured: see the sweep in the design notes)
 template <class M> __device__ __forceinline__ bool jitter_search(const rt_rng_key& key, uint32_t& dim) {
-    uint32_t first = kJitterLook;
-    float r1 = 1.f;
+    // r1 = ((w >> 8) + 1) * 2^-24 >= 0.77f exactly when the generator's word w >= kPass: 0.77f * 2^24 = 12 918 455.36,
+    // so (w >> 8) + 1 >= 12 918 456 (rt_rng_uniform; the comparison on the word saves the conversion per draw)
+    constexpr uint32_t kPass = 12918455u << 8;
+    uint32_t first = kJitterLook, word = 0;
 #pragma unroll
     for (int i = kJitterLook - 1; i >= 0; i--) {
-        const float r = rt_rng_uniform(key, dim + 2 * i);
-        if (r >= 0.77f) { first = (uint32_t)i; r1 = r; }
+        const uint32_t w = rt_rng_word(key, dim + 2 * i);
+        if (w >= kPass) { first = (uint32_t)i; word = w; }
     }
     const uint32_t d = dim + 2 * first;
     if (first == (uint32_t)kJitterLook) { dim = d; return false; }
     dim = d + 2;
+    const float r1 = (float)((word >> 8) + 1U) * 5.9604644775390625e-08f; // rt_rng_uniform(key, d)
     const float r2 = rt_rng_uniform(key, d + 1);
     float radius;
     if constexpr (M::kExact) radius = __builtin_sqrtf(-1.3862944f * __builtin_amdgcn_logf(r1)); // -2 ln 2 * log2(r1)
