@@ -923,7 +923,8 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             if (cull) {
                 const size_t slots = (size_t)n_counters * ws.tiles * kCountStride * sizeof(uint32_t);
                 HIP_TRY(hipMemsetAsync(w.cl_count, 0, slots * s->d.n_clusters, stream));
-                if (s->d.n_groups) HIP_TRY(hipMemsetAsync(w.grp_count, 0, slots * (s->d.n_groups + s->n_super), stream)); // (the super-groups' counters follow)
+                if (s->d.n_groups) HIP_TRY(hipMemsetAsync(w.grp_count, 0, slots * s->d.n_groups, stream));
+                if (s->n_super) HIP_TRY(hipMemsetAsync(ws.sup_count, 0, slots * s->n_super, stream));
             }
         }
         if (stats) {
@@ -1306,7 +1307,8 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
         hipLaunchKernelGGL(k_probe_rays, grid, block, 0, nullptr, s->d, w, f, (const float*)d_a, (const float*)d_b, as_segments);
         const bool cull = opt->cluster_culling != 0 && s->d.n_clusters > 1;
         if (cull && hipMemset(w.cl_count, 0, (size_t)2 * s->ws.tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
-        if (cull && s->d.n_groups && hipMemset(w.grp_count, 0, (size_t)2 * s->ws.tiles * (s->d.n_groups + s->n_super) * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        if (cull && s->d.n_groups && hipMemset(w.grp_count, 0, (size_t)2 * s->ws.tiles * s->d.n_groups * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
+        if (cull && s->n_super && hipMemset(s->ws.sup_count, 0, (size_t)2 * s->ws.tiles * s->n_super * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         if (launch_mesh(s, s->ws, 0, nullptr, false, cull, n, false) != RT_OK) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }

@@ -82,3 +82,25 @@ def test_large_mesh_sums_with_and_without_statistics(tmp_path):
         sums.append(buf.to_host().view(np.uint32).copy())
         assert (st is not None) == want_stats and (st is None or st.triangle_tests > 0)
     assert np.array_equal(sums[0], sums[1]) and np.array_equal(sums[0], sums[2])
+
+
+def test_three_levels_on_a_work_set_laid_out_for_more_stages(tmp_path):
+    """A handle whose work buffers were laid out for a frame of five bounces then renders a frame of two and casts
+    probe rays: the counters of all three culling levels of the stages in use are cleared wherever they lie."""
+    s, _ = scene_with_mesh(tmp_path, 100, 200, rt.DIFFUSE, 64, 48, 2)
+    desc, cam = s.describe()
+    used = s.upload()
+    used.render(cam, rt.make_options(seed=4))
+    shallow = rt.make_options(seed=5, max_depth=2)
+    a, _ = used.render(cam, shallow)
+    b, _ = s.upload().render(cam, shallow)
+    assert same_bits(a, b)
+    rng = np.random.default_rng(7)
+    o = rng.uniform(-35, 35, (400, 3)).astype(np.float32)
+    d = (rng.uniform(-10, 10, (400, 3)) + np.array([0, 2, 8]) - o)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    opt = rt.make_options()
+    t, sid, tid, abg = used.cast(opt, o, d)
+    rt_, rsid, rtid, rabg = ob.cast(desc, ob.from_rt_options(opt), o, d)
+    assert (rtid >= 0).sum() > 100
+    assert np.array_equal(tid, rtid) and np.array_equal(sid, rsid) and same_bits(t, rt_)
