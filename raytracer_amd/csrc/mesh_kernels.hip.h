@@ -192,6 +192,11 @@ __device__ __forceinline__ void pair_hits(const PairData& p, bool live, float ox
 
 // The division-free filter of pair_hits alone: c0 / c1 say whether the ray's line may meet triangle 0 / 1 of the pair
 // (the same packed arithmetic, so the same verdicts).
+// kFused (the fast arithmetic, rt_options.arithmetic = 1): products are fused into the sums that follow them -- a third
+// fewer instructions, numerators and denominator a few units in the last place of their terms away from the reference's.
+// A ray that meets a triangle within that distance of its edge may then be judged the other way, which the fast
+// arithmetic's tolerance covers and the exact arithmetic's bit-for-bit promise does not.
+template <bool kFused>
 __device__ __forceinline__ void pair_filter(const PairData& p, bool live, float ox, float oy, float oz, float ux, float uy, float uz,
                                             bool& c0, bool& c1) {
     const f2 Ax = p.v[0], Ay = p.v[1], Az = p.v[2];
@@ -199,12 +204,23 @@ __device__ __forceinline__ void pair_filter(const PairData& p, bool live, float 
     const f2 e2x = p.v[6], e2y = p.v[7], e2z = p.v[8];
     const f2 Nx = p.v[9], Ny = p.v[10], Nz = p.v[11];
     const f2 aox = Ax - ox, aoy = Ay - oy, aoz = Az - oz;
-    const f2 qx = aoy * uz - aoz * uy;
-    const f2 qy = aoz * ux - aox * uz;
-    const f2 qz = aox * uy - aoy * ux;
-    const f2 d = (ux * Nx + uy * Ny) + uz * Nz;
-    const f2 nb = (e2x * qx + e2y * qy) + e2z * qz; // e2 . q
-    const f2 ng = (e1x * qx + e1y * qy) + e1z * qz; // e1 . q
+    f2 qx, qy, qz, d, nb, ng;
+    if constexpr (kFused) {
+        auto fma2 = [](f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); };
+        qx = fma2(aoy, (f2)(uz), -(aoz * uy));
+        qy = fma2(aoz, (f2)(ux), -(aox * uz));
+        qz = fma2(aox, (f2)(uy), -(aoy * ux));
+        d = fma2((f2)(ux), Nx, fma2((f2)(uy), Ny, uz * Nz));
+        nb = fma2(e2x, qx, fma2(e2y, qy, e2z * qz)); // e2 . q
+        ng = fma2(e1x, qx, fma2(e1y, qy, e1z * qz)); // e1 . q
+    } else {
+        qx = aoy * uz - aoz * uy;
+        qy = aoz * ux - aox * uz;
+        qz = aox * uy - aoy * ux;
+        d = (ux * Nx + uy * Ny) + uz * Nz;
+        nb = (e2x * qx + e2y * qy) + e2z * qz; // e2 . q
+        ng = (e1x * qx + e1y * qy) + e1z * qz; // e1 . q
+    }
     f2 rcp;
     rcp.x = __builtin_amdgcn_rcpf(d.x);
     rcp.y = __builtin_amdgcn_rcpf(d.y);
@@ -761,7 +777,8 @@ __global__ __launch_bounds__(1024) void k_plan_runs(const uint32_t* __restrict__
 
 // kMany: more than kFusedMaxGroups groups (three culling levels) -- the run table comes from k_plan_runs (`plan`, read
 // from memory: a workgroup looks up the one or two runs it takes) instead of being computed by every workgroup.
-template <int R, int T, int U, bool kMany>
+// kFused: the filter of a trip in fused arithmetic (pair_filter; the fast arithmetic only).
+template <int R, int T, int U, bool kMany, bool kFused>
 __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri2, const uint32_t* __restrict__ tri_orig, uint32_t n_tri,
                                                       uint32_t n_clusters, uint32_t cluster_pairs, uint32_t n_groups,
                                                       uint32_t group_clusters, const f2* __restrict__ cl_pair,
@@ -908,7 +925,7 @@ __global__ __launch_bounds__(T) void k_group_clusters(const f2* __restrict__ tri
                         const uint32_t e = refs_s[wave][min(k, n - 1u)];
                         const float4 o4 = ray_s[2 * e], d4 = ray_s[2 * e + 1];
                         bool c0, c1;
-                        pair_filter(pd, k < n, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, c0, c1);
+                        pair_filter<kFused>(pd, k < n, o4.x, o4.y, o4.z, d4.x, d4.y, d4.z, c0, c1);
                         const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
                         if (m0 | m1) {
                             if (n_cand + 128u <= kCandCap) {

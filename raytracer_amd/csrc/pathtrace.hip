@@ -350,10 +350,11 @@ int mark_event(rt_scene* s, hipStream_t stream, char tag) {
 
 // One k_mesh stage: the queued rays of `counter` against the mesh, either by
 // the exhaustive scan or through the cluster lists.
+// fast: rt_options.arithmetic = 1 (the triangle filter of k_group_clusters in fused arithmetic).
 // ray_bound: most rays the stage's queue can hold (0: unknown) -- the camera rays of a batch are at most its paths --,
 // which spares a mesh whose lists need several tiles per stage the launches of tiles that are certainly empty.
 int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t stream, bool profile, bool cull, uint32_t batch_paths,
-                bool count_tests, size_t ray_bound = 0) {
+                bool count_tests, bool fast, size_t ray_bound = 0) {
     const Work& w = ws.w;
     if (s->d.n_triangles == 0) return RT_OK;
     auto mark = [&](char tag) -> int { return profile ? mark_event(s, stream, tag) : RT_OK; };
@@ -405,7 +406,7 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
                 if ((rc = mark('M')) != RT_OK) return rc;
                 const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : batch_paths >= 6u * 1024u * 1024u ? 6144u : batch_paths >= 2u * 1024u * 1024u ? 3072u : 1024u;
                 hipLaunchKernelGGL(k_plan_runs, dim3(1), dim3(1024), 0, stream, (const uint32_t*)grp_count, ng, grid, 1024u, ws.run_plan);
-                hipLaunchKernelGGL((k_group_clusters<2, 512, 2, true>), dim3(grid), dim3(512), 0, stream,
+                hipLaunchKernelGGL((fast ? k_group_clusters<2, 512, 2, true, true> : k_group_clusters<2, 512, 2, true, false>), dim3(grid), dim3(512), 0, stream,
                                    tri2, s->d.tri_orig, s->d.n_triangles, nc,
                                    s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
                                    (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,
@@ -423,7 +424,7 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
                 // 1.03 / 0.91 / 1.13 ms per frame).  Many more workgroups than fit the chip: a run is then one or
                 // two passes and the runs even out (768 / 3 072 / 6 144 workgroups: 1.20 / 0.90 / 0.87 ms).
                 const uint32_t grid = fused_grid > 0 ? (uint32_t)fused_grid : batch_paths >= 6u * 1024u * 1024u ? 6144u : batch_paths >= 2u * 1024u * 1024u ? 3072u : 1024u;
-                hipLaunchKernelGGL((k_group_clusters<2, 512, 2, false>), dim3(grid), dim3(512), 0, stream,
+                hipLaunchKernelGGL((fast ? k_group_clusters<2, 512, 2, false, true> : k_group_clusters<2, 512, 2, false, false>), dim3(grid), dim3(512), 0, stream,
                                    tri2, s->d.tri_orig, s->d.n_triangles, nc,
                                    s->d.cluster_pairs, ng, s->d.group_clusters, cl_pair, (const float4*)w.q_o, (const float4*)w.q_d,
                                    (const uint32_t*)grp_count, (const uint32_t*)w.grp_list, w.list_capacity, w.hit,
@@ -950,7 +951,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             hipLaunchKernelGGL((fast ? (fits ? k_generate<1, FastMath, true> : k_generate<1, FastMath, false>) : (fits ? k_generate<1, ExactMath, true> : k_generate<1, ExactMath, false>)), grid, block, 0, stream, s->d, w, f, regenerate);
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < opt->max_depth; depth++) {
-            if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr, depth == 0 ? f.n_paths : 0)) != RT_OK) return rc;
+            if ((rc = launch_mesh(s, ws, (uint32_t)depth, stream, profile, cull, f.n_paths, stats != nullptr, fast, depth == 0 ? f.n_paths : 0)) != RT_OK) return rc;
             if (profile && (rc = mark_event(s, stream, 'S')) != RT_OK) return rc;
             if (depth == 0 && regenerate) {
                 hipLaunchKernelGGL((fits ? k_shade_fast_first<true> : k_shade_fast_first<false>), grid, block, 0, stream, s->d, w, f);
@@ -969,7 +970,7 @@ int accumulate_batches(rt_scene* s, const WorkSet& ws, BatchShape shape, const r
             if (profile && (rc = mark_event(s, stream, 'E')) != RT_OK) return rc;
             HIP_TRY(hipGetLastError());
         }
-        if ((rc = launch_mesh(s, ws, (uint32_t)opt->max_depth, stream, profile, cull, f.n_paths, stats != nullptr)) != RT_OK) return rc;
+        if ((rc = launch_mesh(s, ws, (uint32_t)opt->max_depth, stream, profile, cull, f.n_paths, stats != nullptr, opt->arithmetic != 0)) != RT_OK) return rc;
         hipLaunchKernelGGL(k_accumulate, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, s->d, w, f,
                            reinterpret_cast<float4*>(d_sum));
         HIP_TRY(hipGetLastError());
@@ -1309,7 +1310,7 @@ int probe(rt_scene* s, const rt_options* opt, uint32_t n, const float* a, const 
         if (cull && hipMemset(w.cl_count, 0, (size_t)2 * s->ws.tiles * s->d.n_clusters * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         if (cull && s->d.n_groups && hipMemset(w.grp_count, 0, (size_t)2 * s->ws.tiles * s->d.n_groups * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
         if (cull && s->n_super && hipMemset(s->ws.sup_count, 0, (size_t)2 * s->ws.tiles * s->n_super * kCountStride * sizeof(uint32_t))) { rc = RT_ERR_DEVICE; break; }
-        if (launch_mesh(s, s->ws, 0, nullptr, false, cull, n, false) != RT_OK) { rc = RT_ERR_DEVICE; break; }
+        if (launch_mesh(s, s->ws, 0, nullptr, false, cull, n, false, opt->arithmetic != 0) != RT_OK) { rc = RT_ERR_DEVICE; break; }
         hipLaunchKernelGGL(k_probe_results, grid, block, 0, nullptr, s->d, w, f, as_segments, d_t, d_s, d_tr, d_abg, d_v);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = RT_ERR_DEVICE; break; }
         if (as_segments) {
