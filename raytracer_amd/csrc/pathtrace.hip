@@ -101,6 +101,11 @@ struct rt_scene {
     // consecutive groups with the union of their bounds, at most 64 of at most 64.  0: two levels.
     uint32_t n_super = 0, super_groups = 0;
     const float2* sup_pair = nullptr;
+    // The bounds of clusters, groups and super-groups once more with the small padding the fast arithmetic needs
+    // (rt_scene_upload); d.cl_pair, d.grp_pair and sup_pair carry the padding of the exact arithmetic.
+    const float2* cl_pair_tight = nullptr;
+    const float2* grp_pair_tight = nullptr;
+    const float2* sup_pair_tight = nullptr;
     // profiling events
     std::vector<hipEvent_t> events;   // pool, reused by every call
     std::vector<char> event_tags;     // tag of the events in use, in record order
@@ -371,7 +376,7 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
             const size_t slot = (size_t)counter * ws.tiles + tile;
             uint32_t* cl_count = w.cl_count + slot * nc * kCountStride;
             if ((rc = mark('B')) != RT_OK) return rc;
-            const f2* cl_pair = reinterpret_cast<const f2*>(s->d.cl_pair);
+            const f2* cl_pair = reinterpret_cast<const f2*>(fast ? s->cl_pair_tight : s->d.cl_pair);
             // two ray blocks per workgroup, except for short batches (measured: better from about 2 M paths up)
             bool wide = batch_paths >= 1536u * 1024u;
             bool wider = batch_paths >= 6u * 1024u * 1024u;
@@ -389,14 +394,14 @@ int launch_mesh(rt_scene* s, const WorkSet& ws, uint32_t counter, hipStream_t st
             auto bin64 = wider ? k_bin64<4> : wide ? k_bin64<2> : k_bin64<1>;
             const uint32_t ng = s->d.n_groups;
             uint32_t* grp_count = w.grp_count + slot * ng * kCountStride;
-            const f2* grp_pair = reinterpret_cast<const f2*>(s->d.grp_pair);
+            const f2* grp_pair = reinterpret_cast<const f2*>(fast ? s->grp_pair_tight : s->d.grp_pair);
             static const int fused_grid = [] { const char* e = std::getenv("RT_AMD_FUSED_GRID"); return e ? std::atoi(e) : 0; }(); // tuning knob
             if (s->n_super) {
                 // three levels: the rays against the super-groups, each super-group's list against its groups (lists in
                 // global memory both), then the groups' lists against their clusters and the clusters' triangles
                 // (k_group_clusters, the last level in LDS), with the table of runs made once by k_plan_runs
                 uint32_t* sup_count = ws.sup_count + slot * s->n_super * kCountStride;
-                hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(s->sup_pair), s->n_super,
+                hipLaunchKernelGGL(bin64, dim3(bin_grid), dim3(kBlock), 0, stream, reinterpret_cast<const f2*>(fast ? s->sup_pair_tight : s->sup_pair), s->n_super,
                                    (const float4*)w.q_o, (const float4*)w.q_d, q_count, w.shard_capacity,
                                    tile * blocks_per_tile, blocks_per_tile, sup_count, ws.sup_list, w.list_capacity);
                 auto bin_groups = wider ? k_bin_groups<4> : wide ? k_bin_groups<2> : k_bin_groups<1>;
@@ -686,36 +691,6 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
         }
     }
     const uint32_t n_clusters = (uint32_t)((n_pairs + cluster_pairs - 1) / cluster_pairs);
-    std::vector<float4> cl_min(n_clusters), cl_max(n_clusters);
-    for (uint32_t c = 0; c < n_clusters; c++) {
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        const size_t begin = (size_t)c * cluster_pairs * 2;
-        const size_t end = std::min<size_t>(begin + (size_t)cluster_pairs * 2, d->n_triangles);
-        for (size_t pos = begin; pos < end; pos++)
-            for (int k = 0; k < 3; k++) {
-                const float* v = d->vertices + 3 * d->tri_v[3 * order[pos] + k];
-                for (int a = 0; a < 3; a++) {
-                    if (v[a] < lo[a]) lo[a] = v[a];
-                    if (v[a] > hi[a]) hi[a] = v[a];
-                }
-            }
-        const float diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-        const float pad = 0.05f + 1e-3f * diag;
-        cl_min[c] = make_float4(lo[0] - pad, lo[1] - pad, lo[2] - pad, 0.f);
-        cl_max[c] = make_float4(hi[0] + pad, hi[1] + pad, hi[2] + pad, 0.f);
-    }
-    // the same bounds, two clusters per entry for k_bin64; the unused half of
-    // the last entry of an odd count is never read as a cluster (k_bin64 skips it)
-    std::vector<float2> cl_pair(6 * (((size_t)n_clusters + 1) / 2), make_float2(1e30f, 1e30f));
-    for (uint32_t c = 0; c < ((n_clusters + 1) / 2) * 2; c++) {
-        const bool real = c < n_clusters;
-        const float v[6] = {real ? cl_min[c].x : 1e30f, real ? cl_min[c].y : 1e30f, real ? cl_min[c].z : 1e30f,
-                            real ? cl_max[c].x : -1e30f, real ? cl_max[c].y : -1e30f, real ? cl_max[c].z : -1e30f};
-        for (int k = 0; k < 6; k++) {
-            float2& dst = cl_pair[6 * (size_t)(c / 2) + k];
-            if (c & 1) dst.y = v[k]; else dst.x = v[k];
-        }
-    }
     // Groups of consecutive clusters with the union of their bounds.  Up to kFusedMaxGroups * kFusedGroup
     // clusters: groups of kFusedGroup clusters, binned and scanned by one kernel (k_group_clusters).
     // Beyond: about sqrt(n) groups of sqrt(n) clusters (an even number, so that a group starts a box
@@ -727,38 +702,84 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
         if (v >= 2 && v <= (fused ? (long)kFusedGroup : 64) && v % 2 == 0 && (n_clusters + v - 1) / v <= 64) group_clusters = (uint32_t)v;
     }
     const uint32_t n_groups = n_clusters > 1 ? (n_clusters + group_clusters - 1) / group_clusters : 0;
-    std::vector<float2> grp_pair(6 * (((size_t)n_groups + 1) / 2), make_float2(0.f, 0.f));
-    for (uint32_t g = 0; g < n_groups; g++) {
-        float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t c = g * group_clusters; c < std::min(n_clusters, (g + 1) * group_clusters); c++) {
-            const float lo[3] = {cl_min[c].x, cl_min[c].y, cl_min[c].z}, hi[3] = {cl_max[c].x, cl_max[c].y, cl_max[c].z};
-            for (int a = 0; a < 3; a++) {
-                if (lo[a] < v[a]) v[a] = lo[a];
-                if (hi[a] > v[3 + a]) v[3 + a] = hi[a];
+    // The bounds of the clusters (padded by pad_abs plus pad_rel of the cluster's diagonal), of the groups and of the
+    // super-groups.  Built twice: with the padding the exact arithmetic needs -- 0.05 plus a thousandth of the diagonal,
+    // so that no triangle the reference's own rounding accepts for a ray just outside its true bounds is lost -- and
+    // with a small one for the fast arithmetic, whose filter only has to absorb its own rounding (relative 1e-6 of the
+    // coordinates at most): a ten-thousandth of the largest coordinate or extent.  Tighter bounds: 3 % fewer list
+    // entries and tests on the cat.
+    auto build_bounds = [&](float pad_abs, float pad_rel, std::vector<float2>& cl_pair, std::vector<float2>& grp_pair,
+                            std::vector<float2>& sup_pair) {
+        std::vector<float4> cl_min(n_clusters), cl_max(n_clusters);
+        for (uint32_t c = 0; c < n_clusters; c++) {
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            const size_t begin = (size_t)c * cluster_pairs * 2;
+            const size_t end = std::min<size_t>(begin + (size_t)cluster_pairs * 2, d->n_triangles);
+            for (size_t pos = begin; pos < end; pos++)
+                for (int k = 0; k < 3; k++) {
+                    const float* v = d->vertices + 3 * d->tri_v[3 * order[pos] + k];
+                    for (int a = 0; a < 3; a++) {
+                        if (v[a] < lo[a]) lo[a] = v[a];
+                        if (v[a] > hi[a]) hi[a] = v[a];
+                    }
+                }
+            const float diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+            const float pad = pad_abs + pad_rel * diag;
+            cl_min[c] = make_float4(lo[0] - pad, lo[1] - pad, lo[2] - pad, 0.f);
+            cl_max[c] = make_float4(hi[0] + pad, hi[1] + pad, hi[2] + pad, 0.f);
+        }
+        // the same bounds, two clusters per entry for k_bin64; the unused half of
+        // the last entry of an odd count is never read as a cluster (k_bin64 skips it)
+        cl_pair.assign(6 * (((size_t)n_clusters + 1) / 2), make_float2(1e30f, 1e30f));
+        for (uint32_t c = 0; c < ((n_clusters + 1) / 2) * 2; c++) {
+            const bool real = c < n_clusters;
+            const float v[6] = {real ? cl_min[c].x : 1e30f, real ? cl_min[c].y : 1e30f, real ? cl_min[c].z : 1e30f,
+                                real ? cl_max[c].x : -1e30f, real ? cl_max[c].y : -1e30f, real ? cl_max[c].z : -1e30f};
+            for (int k = 0; k < 6; k++) {
+                float2& dst = cl_pair[6 * (size_t)(c / 2) + k];
+                if (c & 1) dst.y = v[k]; else dst.x = v[k];
             }
         }
-        for (int k = 0; k < 6; k++) {
-            float2& dst = grp_pair[6 * (size_t)(g / 2) + k];
-            if (g & 1) dst.y = v[k]; else dst.x = v[k];
-        }
-    }
-    // Three levels: super-groups of consecutive groups, the union of their clusters' bounds.
-    std::vector<float2> sup_pair(6 * (((size_t)n_super + 1) / 2), make_float2(0.f, 0.f));
-    for (uint32_t u = 0; u < n_super; u++) {
-        float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        const uint32_t per = super_groups * group_clusters;
-        for (uint32_t c = u * per; c < std::min(n_clusters, (u + 1) * per); c++) {
-            const float lo[3] = {cl_min[c].x, cl_min[c].y, cl_min[c].z}, hi[3] = {cl_max[c].x, cl_max[c].y, cl_max[c].z};
-            for (int a = 0; a < 3; a++) {
-                if (lo[a] < v[a]) v[a] = lo[a];
-                if (hi[a] > v[3 + a]) v[3 + a] = hi[a];
+        grp_pair.assign(6 * (((size_t)n_groups + 1) / 2), make_float2(0.f, 0.f));
+        for (uint32_t g = 0; g < n_groups; g++) {
+            float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t c = g * group_clusters; c < std::min(n_clusters, (g + 1) * group_clusters); c++) {
+                const float lo[3] = {cl_min[c].x, cl_min[c].y, cl_min[c].z}, hi[3] = {cl_max[c].x, cl_max[c].y, cl_max[c].z};
+                for (int a = 0; a < 3; a++) {
+                    if (lo[a] < v[a]) v[a] = lo[a];
+                    if (hi[a] > v[3 + a]) v[3 + a] = hi[a];
+                }
+            }
+            for (int k = 0; k < 6; k++) {
+                float2& dst = grp_pair[6 * (size_t)(g / 2) + k];
+                if (g & 1) dst.y = v[k]; else dst.x = v[k];
             }
         }
-        for (int k = 0; k < 6; k++) {
-            float2& dst = sup_pair[6 * (size_t)(u / 2) + k];
-            if (u & 1) dst.y = v[k]; else dst.x = v[k];
+        // Three levels: super-groups of consecutive groups, the union of their clusters' bounds.
+        sup_pair.assign(6 * (((size_t)n_super + 1) / 2), make_float2(0.f, 0.f));
+        for (uint32_t u = 0; u < n_super; u++) {
+            float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            const uint32_t per = super_groups * group_clusters;
+            for (uint32_t c = u * per; c < std::min(n_clusters, (u + 1) * per); c++) {
+                const float lo[3] = {cl_min[c].x, cl_min[c].y, cl_min[c].z}, hi[3] = {cl_max[c].x, cl_max[c].y, cl_max[c].z};
+                for (int a = 0; a < 3; a++) {
+                    if (lo[a] < v[a]) v[a] = lo[a];
+                    if (hi[a] > v[3 + a]) v[3 + a] = hi[a];
+                }
+            }
+            for (int k = 0; k < 6; k++) {
+                float2& dst = sup_pair[6 * (size_t)(u / 2) + k];
+                if (u & 1) dst.y = v[k]; else dst.x = v[k];
+            }
         }
-    }
+    };
+    std::vector<float2> cl_pair, grp_pair, sup_pair, cl_pair_tight, grp_pair_tight, sup_pair_tight;
+    build_bounds(0.05f, 1e-3f, cl_pair, grp_pair, sup_pair);
+    float scale = 0.f; // largest coordinate or extent of the mesh
+    for (int a = 0; a < 3; a++)
+        if (d->n_triangles) scale = std::max(scale, std::max(std::max(std::fabs(mesh_lo[a]), std::fabs(mesh_hi[a])), mesh_hi[a] - mesh_lo[a]));
+    if (!(scale < INFINITY)) scale = 0.f; // (non-finite coordinates: the exact padding's bounds are as good as any)
+    build_bounds(1e-4f * scale, 1e-5f, cl_pair_tight, grp_pair_tight, sup_pair_tight);
     std::vector<float4> box_min(d->n_boxes), box_max(d->n_boxes), light(d->n_lights);
     for (uint32_t i = 0; i < d->n_boxes; i++) {
         box_min[i] = make_float4(d->box_min[3 * i], d->box_min[3 * i + 1], d->box_min[3 * i + 2], 0.f);
@@ -784,7 +805,9 @@ extern "C" int rt_scene_upload(const rt_scene_desc* d, rt_scene** out) {
     if ((rc = upload(s, sphere, &s->d.sphere)) || (rc = upload(s, sphere_mat, &s->d.sphere_mat)) ||
         (rc = upload(s, mat_color, &s->d.mat_color)) || (rc = upload(s, mat_ior, &s->d.mat_ior)) ||
         (rc = upload(s, geom, &s->d.tri_geom)) || (rc = upload(s, pair, &s->d.tri_pair)) || (rc = upload(s, orig, &s->d.tri_orig)) ||
-        (rc = upload(s, cl_pair, &s->d.cl_pair)) || (rc = upload(s, grp_pair, &s->d.grp_pair)) || (rc = upload(s, sup_pair, &s->sup_pair)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
+        (rc = upload(s, cl_pair, &s->d.cl_pair)) || (rc = upload(s, grp_pair, &s->d.grp_pair)) || (rc = upload(s, sup_pair, &s->sup_pair)) ||
+        (rc = upload(s, cl_pair_tight, &s->cl_pair_tight)) || (rc = upload(s, grp_pair_tight, &s->grp_pair_tight)) ||
+        (rc = upload(s, sup_pair_tight, &s->sup_pair_tight)) || (rc = upload(s, shade, &s->d.tri_shade)) ||
         (rc = upload(s, box_min, &s->d.box_min)) || (rc = upload(s, box_max, &s->d.box_max)) ||
         (rc = upload(s, light, &s->d.light))) {
         rt_scene_free(s);
